@@ -1,0 +1,72 @@
+// Shared host/device helpers for libccnn_hip (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/ccnn.h"
+
+namespace ccnn {
+
+constexpr int F = CCNN_FILTERS;       // 20 filters
+constexpr int K = CCNN_FILTER_SIZE;   // 171 taps = 19 bands x 9 neighbours
+constexpr int H = CCNN_HIDDEN;        // 100
+constexpr int O = CCNN_CLASSES;       // 13
+constexpr int NB = CCNN_PER_LAYER;    // 9 values per band
+constexpr int WSTEP = NB * CCNN_STRIDE;  // 18: cube offset between conv windows
+constexpr int PCHUNK = 64;            // pooled features per FC1 K-chunk
+
+struct Dims : ccnn_dims_t {};
+
+inline int make_dims(int z, ccnn_dims_t *d)
+{
+    if (!d || z < CCNN_MIN_BANDS || z > CCNN_MAX_BANDS) return CCNN_E_INVALID;
+    d->z = z;
+    d->cube = NB * z;
+    d->re = (z - CCNN_COV_LEN - 1) / CCNN_STRIDE + 1;   // gcn_mbgd_fp64.cu:199
+    d->mre = (d->re - 1) / CCNN_POOL_LEN + 1;
+    d->pin = d->re * F;
+    d->pout = d->mre * F;
+    d->off_w0 = 0;
+    d->off_b0 = d->off_w0 + F * K;
+    d->off_w1 = d->off_b0 + F;
+    d->off_b1 = d->off_w1 + d->pout * H;
+    d->off_w2 = d->off_b1 + H;
+    d->off_b2 = d->off_w2 + H * O;
+    d->nparams = d->off_b2 + O;
+    return 0;
+}
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+inline int nchunks(int pout) { return (pout + PCHUNK - 1) / PCHUNK; }
+
+// Carves typed sub-buffers out of a caller-provided workspace.
+struct Carver {
+    char *base;
+    size_t off = 0;
+    explicit Carver(void *p) : base(static_cast<char *>(p)) {}
+    template <typename T>
+    T *take(size_t n)
+    {
+        T *r = reinterpret_cast<T *>(base + off);
+        off = align_up(off + n * sizeof(T));
+        return r;
+    }
+};
+
+#define CCNN_LAUNCH_CHECK()                         \
+    do {                                            \
+        hipError_t e_ = hipGetLastError();          \
+        if (e_ != hipSuccess) return (int)e_;       \
+    } while (0)
+
+#ifdef __HIPCC__
+// tanh in the reference's spelling (gcn_mbgd_fp64.cu:233): 2/(1+1/exp(2v)) - 1.
+__device__ __forceinline__ float act(float v) { return 2.0f / (1.0f + (1.0f / expf(2.0f * v))) - 1.0f; }
+__device__ __forceinline__ double act(double v) { return 2.0 / (1.0 + (1.0 / exp(2.0 * v))) - 1.0; }
+__device__ __forceinline__ float rexp(float v) { return expf(v); }
+__device__ __forceinline__ double rexp(double v) { return exp(v); }
+#endif
+
+}  // namespace ccnn

@@ -1,0 +1,172 @@
+"""Tensor-level operators over libccnn_hip.so.
+
+Each function takes CUDA (ROCm) torch tensors, checks shapes/dtypes on the host
+so that a kernel never sees an operand it was not written for, and enqueues the
+work on torch's current stream.  Names follow the reference's kernel groups:
+gather (preprocessing), forward (the test loop), sgd, mbgd_grad, update.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as _l
+
+_F32, _F64 = torch.float32, torch.float64
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _req(t, dtype, name, numel=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError(f"{name} must be a CUDA tensor")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    if numel is not None and t.numel() != numel:
+        raise ValueError(f"{name} has {t.numel()} elements, expected {numel}")
+    return t
+
+
+def _sfx(dtype):
+    if dtype == _F32:
+        return "f32", 4
+    if dtype == _F64:
+        return "f64", 8
+    raise TypeError(f"unsupported dtype {dtype}")
+
+
+class Workspace:
+    """A reusable device scratch buffer (grown on demand, never shrunk)."""
+
+    def __init__(self, device="cuda"):
+        self.device = device
+        self.buf = None
+
+    def get(self, nbytes):
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
+        return self.buf
+
+
+def gather(scene, idx9, x, y, z, out=None):
+    """scene: flat [z*y*x] (x fastest); idx9 int32 [n, 9] -> cubes [n, 9z]."""
+    sfx, _ = _sfx(scene.dtype)
+    _req(scene, scene.dtype, "scene", x * y * z)
+    _req(idx9, torch.int32, "idx9")
+    n = idx9.numel() // 9
+    if idx9.numel() != n * 9:
+        raise ValueError("idx9 must hold 9 indices per sample")
+    if out is None:
+        out = torch.empty((n, 9 * z), dtype=scene.dtype, device=scene.device)
+    _req(out, scene.dtype, "out", n * 9 * z)
+    fn = getattr(_l.load(), f"ccnn_gather_{sfx}")
+    _l.check(fn(_ptr(scene), _ptr(idx9), n, x, y, z, _ptr(out), _stream()), f"ccnn_gather_{sfx}")
+    return out
+
+
+def forward(params, cubes, z, want_probs=True, want_argmax=True, workspace=None):
+    """Test-loop forward over cubes [n, 9z] -> (probs [n,13] | None, argmax int32 [n] | None)."""
+    sfx, es = _sfx(params.dtype)
+    d = _l.dims(z)
+    _req(params, params.dtype, "params", d.nparams)
+    n = cubes.numel() // d.cube
+    _req(cubes, params.dtype, "cubes", n * d.cube)
+    probs = torch.empty((n, 13), dtype=params.dtype, device=params.device) if want_probs else None
+    argmax = torch.empty(n, dtype=torch.int32, device=params.device) if want_argmax else None
+    if n == 0:
+        return probs, argmax
+    lib = _l.load()
+    nbytes = lib.ccnn_forward_workspace_bytes(n, z, es)
+    ws = (workspace or Workspace(params.device)).get(nbytes)
+    fn = getattr(lib, f"ccnn_forward_{sfx}")
+    _l.check(fn(_ptr(params), _ptr(cubes), n, z, _ptr(probs), _ptr(argmax), _ptr(ws), ws.numel(), _stream()),
+             f"ccnn_forward_{sfx}")
+    return probs, argmax
+
+
+def count_correct(argmax, labels):
+    """Device count of argmax+1 == labels; returns a 1-element int32 tensor."""
+    _req(argmax, torch.int32, "argmax")
+    _req(labels, torch.int32, "labels", argmax.numel())
+    count = torch.empty(1, dtype=torch.int32, device=argmax.device)
+    _l.check(_l.load().ccnn_count_correct(_ptr(argmax), _ptr(labels), argmax.numel(), _ptr(count), _stream()),
+             "ccnn_count_correct")
+    return count
+
+
+def sgd(params, cubes, onehot, first, count, z, lr, loss, workspace=None):
+    """fp64 per-sample SGD over samples [first, first+count); params and the
+    1-element fp64 tensor `loss` are updated in place."""
+    d = _l.dims(z)
+    _req(params, _F64, "params", d.nparams)
+    n = cubes.numel() // d.cube
+    _req(cubes, _F64, "cubes", n * d.cube)
+    _req(onehot, torch.int32, "onehot", n * 13)
+    _req(loss, _F64, "loss", 1)
+    if first < 0 or count < 0 or first + count > n:
+        raise ValueError(f"samples [{first}, {first + count}) outside [0, {n})")
+    lib = _l.load()
+    ws = (workspace or Workspace(params.device)).get(lib.ccnn_sgd_workspace_bytes(z))
+    _l.check(lib.ccnn_sgd_f64(_ptr(params), _ptr(cubes), _ptr(onehot), first, count, z, float(lr), _ptr(loss),
+                              _ptr(ws), ws.numel(), _stream()), "ccnn_sgd_f64")
+
+
+def mbgd_grad(params, cubes, onehot, first, B, z, grad=None, loss_values=None, probs=None, workspace=None):
+    """Batch-summed gradient of samples [first, first+B) -> (grad, loss_values[B] fp64)."""
+    sfx, es = _sfx(params.dtype)
+    d = _l.dims(z)
+    _req(params, params.dtype, "params", d.nparams)
+    n = cubes.numel() // d.cube
+    _req(cubes, params.dtype, "cubes", n * d.cube)
+    _req(onehot, torch.int32, "onehot", n * 13)
+    if B <= 0 or first < 0 or first + B > n:
+        raise ValueError(f"batch [{first}, {first + B}) outside [0, {n})")
+    if grad is None:
+        grad = torch.empty(d.nparams, dtype=params.dtype, device=params.device)
+    _req(grad, params.dtype, "grad", d.nparams)
+    if loss_values is None:
+        loss_values = torch.empty(B, dtype=_F64, device=params.device)
+    _req(loss_values, _F64, "loss_values")
+    if loss_values.numel() < B:
+        raise ValueError("loss_values shorter than the batch")
+    if probs is not None:
+        _req(probs, params.dtype, "probs", B * 13)
+    lib = _l.load()
+    ws = (workspace or Workspace(params.device)).get(lib.ccnn_mbgd_workspace_bytes(B, z, es))
+    fn = getattr(lib, f"ccnn_mbgd_grad_{sfx}")
+    _l.check(fn(_ptr(params), _ptr(cubes), _ptr(onehot), first, B, z, _ptr(grad), _ptr(loss_values), _ptr(probs),
+                _ptr(ws), ws.numel(), _stream()), f"ccnn_mbgd_grad_{sfx}")
+    return grad, loss_values
+
+
+def update(params, grad, lr, z, divisor=None, freeze_conv_bias=True):
+    """fp64: params -= lr*grad/divisor.  fp32: params -= lr*grad with the conv bias
+    left untouched (the fp32 reference never updates it)."""
+    d = _l.dims(z)
+    _req(params, params.dtype, "params", d.nparams)
+    _req(grad, params.dtype, "grad", d.nparams)
+    lib = _l.load()
+    if params.dtype == _F64:
+        if not divisor or divisor <= 0:
+            raise ValueError("fp64 update needs the batch size as divisor")
+        _l.check(lib.ccnn_update_f64(_ptr(params), _ptr(grad), float(lr), int(divisor), d.nparams, _stream()),
+                 "ccnn_update_f64")
+    else:
+        _sfx(params.dtype)
+        _l.check(lib.ccnn_update_f32(_ptr(params), _ptr(grad), float(lr), z, int(bool(freeze_conv_bias)),
+                                     _stream()), "ccnn_update_f32")
+
+
+def update_adagrad(params, rms, grad, lr, it):
+    _req(params, _F64, "params")
+    _req(rms, _F64, "rms", params.numel())
+    _req(grad, _F64, "grad", params.numel())
+    _l.check(_l.load().ccnn_update_adagrad_f64(_ptr(params), _ptr(rms), _ptr(grad), float(lr), int(it),
+                                               params.numel(), _stream()), "ccnn_update_adagrad_f64")

@@ -1,0 +1,217 @@
+"""GPU: the HIP library (through the C ABI) against the CPU oracle and the golden
+fixtures.  Tolerances: gather / labels / indices bit-exact; fp64 weights, losses
+and probabilities 1e-12 relative to the tensor's largest magnitude; fp32 1e-5.
+argmax must agree wherever the oracle's top-2 margin exceeds the tolerance."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as orc
+import synth
+from gcn_amd import ops, prep
+
+pytestmark = pytest.mark.gpu
+
+TOL = {np.float64: 1e-12, np.float32: 1e-5}
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def assert_argmax(am_gpu, am_ref, probs_ref, tol):
+    top2 = np.sort(probs_ref, axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 10 * tol * top2[:, 1]
+    assert np.array_equal(am_gpu[clear], am_ref[clear])
+    assert clear.mean() > 0.9      # near-ties are rare; the check must not be vacuous
+
+
+def make_problem(z, n, seed, dtype):
+    rng = np.random.default_rng(seed)
+    cubes = rng.random((n, 9 * z)).astype(dtype)
+    onehot = np.zeros((n, 13), dtype=np.int32)
+    onehot[np.arange(n), rng.integers(0, 13, n)] = 1
+    orc.srand(seed)
+    params = orc.init_params_f64(z, 0) if dtype == np.float64 else orc.init_params_f32(z)
+    return params, cubes, onehot
+
+
+# --------------------------------------------------------------------------- gather
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("name", ["index_7x6x24.npz", "index_16x12x176.npz"])
+def test_gather_golden_bit_exact(golden, name, dtype):
+    g = golden(name)
+    x, y, z, seed = int(g["x"]), int(g["y"]), int(g["z"]), int(g["seed"])
+    scene, _ = synth.small_scene(x, y, z, seed)
+    scene = scene.astype(dtype)
+    for key in ("train_idx9", "test_idx9"):
+        idx = g[key]
+        out = ops.gather(dev(scene), dev(idx), x, y, z).cpu().numpy()
+        ref = orc.gather(scene, idx, x, y, z)
+        assert out.tobytes() == ref.tobytes()
+        if dtype == np.float64 and "train_cubes" in g and key == "train_idx9":
+            assert out.tobytes() == g["train_cubes"].tobytes()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_gather_ragged_and_empty(dtype):
+    x, y, z = 37, 29, 103
+    scene, labels = synth.small_scene(x, y, z, 5, dtype)
+    di = prep.scan_labels(labels, x, y)
+    tr9, te9, _, _ = prep.build_index(labels, di, x, y)
+    for idx in (tr9, te9, tr9[:1], tr9[:0]):
+        out = ops.gather(dev(scene), dev(idx.reshape(-1, 9)), x, y, z).cpu().numpy()
+        assert out.tobytes() == orc.gather(scene, idx.reshape(-1, 9), x, y, z).tobytes()
+
+
+def test_gather_full_size_property():
+    """Indian-Pines-sized scene: gather equals plain indexing (a pure copy), checked on the device."""
+    x, y, z, nl = synth.SCENES["indian_pines"]
+    rng = np.random.default_rng(20243)
+    labels = synth.make_labels(x, y, nl, rng)
+    scene = synth.make_scene(x, y, z, np.float32, rng)
+    di = prep.scan_labels(labels, x, y)
+    tr9, te9, _, _ = prep.build_index(labels, di, x, y)
+    prep.shuffle(tr9, np.zeros((len(tr9), 13), dtype=np.int32), 1)
+    sc = dev(scene)
+    out = ops.gather(sc, dev(tr9), x, y, z)
+    ref = sc.view(z, x * y)[:, dev(tr9).long()].permute(1, 0, 2).reshape(len(tr9), 9 * z)
+    assert torch.equal(out, ref)
+    # centre-pixel spectrum of every sample equals the scene's spectrum at that pixel
+    assert torch.equal(out.view(-1, z, 9)[:, :, 4], sc.view(z, x * y)[:, dev(tr9[:, 4]).long()].t())
+
+
+# --------------------------------------------------------------------------- forward
+def test_forward_ksc_checkpoint(golden):
+    g = golden("ksc_forward.npz")
+    z = int(g["z"])
+    probs, am = ops.forward(dev(g["params"]), dev(g["cubes"]), z)
+    assert relerr(probs.cpu().numpy(), g["probs"]) < 1e-12
+    assert np.array_equal(am.cpu().numpy(), g["argmax"])
+
+
+@pytest.mark.parametrize("dtype,z,n", [(np.float64, 176, 67), (np.float32, 200, 130), (np.float32, 103, 33),
+                                       (np.float64, 21, 5), (np.float32, 224, 17), (np.float64, 22, 3)])
+def test_forward_matches_oracle(dtype, z, n):
+    params, cubes, _ = make_problem(z, n, 100 + z, dtype)
+    params = (params * 5).astype(dtype)          # spread the probabilities
+    pr, am = orc.forward(params, cubes, z)
+    probs, argmax = ops.forward(dev(params), dev(cubes), z)
+    assert relerr(probs.cpu().numpy(), pr) < TOL[dtype]
+    assert_argmax(argmax.cpu().numpy(), am, pr, TOL[dtype])
+    # optional outputs
+    p2, a2 = ops.forward(dev(params), dev(cubes), z, want_probs=False)
+    assert p2 is None and torch.equal(a2, argmax)
+
+
+def test_forward_chunked_large_batch():
+    """More samples than one workspace chunk; every chunk must agree with a direct call."""
+    z, n = 103, 20000
+    params, cubes, _ = make_problem(z, 64, 9, np.float32)
+    big = np.tile(cubes, (n // 64 + 1, 1))[:n]
+    probs, am = ops.forward(dev(params), dev(big), z)
+    p64, a64 = ops.forward(dev(params), dev(cubes), z)
+    assert torch.equal(probs.view(-1)[:64 * 13], p64.view(-1))
+    assert torch.equal(probs[-(n % 64):], p64[:n % 64])
+    labels = dev((orc.forward(params, cubes, z)[1] + 1).astype(np.int32))
+    cnt = ops.count_correct(am[:64].contiguous(), labels)
+    assert int(cnt.item()) == 64
+    assert int(ops.count_correct(am[:0].contiguous(), labels[:0].contiguous()).item()) == 0
+
+
+# --------------------------------------------------------------------------- MBGD
+@pytest.mark.parametrize("dtype,key,lr", [(np.float64, "mbgd64", 0.5), (np.float32, "mbgd32", 0.04)])
+def test_mbgd_golden(golden, dtype, key, lr):
+    g = golden("train_small.npz")
+    z = int(g["z"])
+    cubes = dev(g["cubes"].astype(dtype))
+    onehot = dev(g["onehot"])
+    params = dev(g[f"{key}_p0"])
+    for i0 in range(2):
+        grad, lv = ops.mbgd_grad(params, cubes, onehot, i0 * 4, 4, z)
+        assert relerr(grad.cpu().numpy(), g[f"{key}_grad{i0}"]) < TOL[dtype]
+        assert relerr(lv.cpu().numpy(), g[f"{key}_loss"][i0]) < TOL[dtype]
+        ops.update(params, grad, lr, z, divisor=4)
+    assert relerr(params.cpu().numpy(), g[f"{key}_p2"]) < TOL[dtype]
+    d = orc.dims(z)
+    if dtype == np.float32:
+        assert np.all(params.cpu().numpy()[d.off_b0:d.off_w1] == 0)
+
+
+@pytest.mark.parametrize("dtype,z,B,lr", [(np.float64, 176, 100, 0.5), (np.float32, 200, 128, 0.04),
+                                          (np.float32, 103, 128, 0.04), (np.float64, 103, 37, 0.5),
+                                          (np.float32, 224, 16, 0.04), (np.float32, 21, 5, 0.04)])
+def test_mbgd_steps_match_oracle(dtype, z, B, lr):
+    steps = 3
+    params, cubes, onehot = make_problem(z, B * steps, 7 + z, dtype)
+    p_ref = params.copy()
+    p_gpu, c_gpu, o_gpu = dev(params), dev(cubes), dev(onehot)
+    ws = ops.Workspace()
+    for i0 in range(steps):
+        lv_ref, pr_ref, g_ref = orc.mbgd_step(p_ref, cubes, onehot, i0 * B, B, z, dtype(lr))
+        probs = torch.empty((B, 13), dtype=p_gpu.dtype, device="cuda")
+        grad, lv = ops.mbgd_grad(p_gpu, c_gpu, o_gpu, i0 * B, B, z, probs=probs, workspace=ws)
+        assert relerr(grad.cpu().numpy(), g_ref) < TOL[dtype], i0
+        assert relerr(lv.cpu().numpy(), lv_ref) < TOL[dtype], i0
+        assert relerr(probs.cpu().numpy(), pr_ref) < TOL[dtype], i0
+        ops.update(p_gpu, grad, lr, z, divisor=B)
+        assert relerr(p_gpu.cpu().numpy(), p_ref) < TOL[dtype], i0
+
+
+def test_adagrad_update_matches_oracle():
+    rng = np.random.default_rng(1)
+    n = 5000
+    p, r, g = rng.normal(size=n), np.abs(rng.normal(size=n)), rng.normal(size=n)
+    pg, rg = dev(p), dev(r)
+    for it in (1, 2, 3):
+        orc.adagrad_update_f64(p, r, g, 0.2, it)
+        ops.update_adagrad(pg, rg, dev(g), 0.2, it)
+    assert relerr(pg.cpu().numpy(), p) < 1e-14 and relerr(rg.cpu().numpy(), r) < 1e-14
+
+
+# --------------------------------------------------------------------------- SGD
+def test_sgd_golden(golden):
+    g = golden("train_small.npz")
+    z = int(g["z"])
+    params = dev(g["sgd_p0"])
+    loss = torch.zeros(1, dtype=torch.float64, device="cuda")
+    ops.sgd(params, dev(g["cubes"]), dev(g["onehot"]), 0, 3, z, 0.008, loss)
+    assert relerr(params.cpu().numpy(), g["sgd_p3"]) < 1e-12
+    assert abs(loss.item() - float(g["sgd_loss"])) < 1e-12 * abs(float(g["sgd_loss"]))
+
+
+@pytest.mark.parametrize("z,n", [(176, 40), (103, 25), (21, 6)])
+def test_sgd_matches_oracle_across_calls(z, n):
+    params, cubes, onehot = make_problem(z, n, 31 + z, np.float64)
+    d = orc.dims(z)
+    p_ref = params.copy()
+    l_ref = orc.sgd_f64(p_ref, cubes, onehot, 0, n, z, 0.008)
+    p_gpu = dev(params)
+    loss = torch.full((1,), 123.0, dtype=torch.float64, device="cuda")   # sample 0 must reset it
+    half = n // 2
+    ws = ops.Workspace()
+    ops.sgd(p_gpu, dev(cubes), dev(onehot), 0, half, z, 0.008, loss, workspace=ws)
+    ops.sgd(p_gpu, dev(cubes), dev(onehot), half, n - half, z, 0.008, loss, workspace=ws)
+    out = p_gpu.cpu().numpy()
+    for lo, hi in ((0, d.off_b0), (d.off_b0, d.off_w1), (d.off_w1, d.off_b1), (d.off_b1, d.off_w2),
+                   (d.off_w2, d.off_b2), (d.off_b2, d.nparams)):
+        assert relerr(out[lo:hi], p_ref[lo:hi]) < 1e-12, (lo, hi)
+    assert abs(loss.item() - l_ref) < 1e-12 * abs(l_ref)
+
+
+# --------------------------------------------------------------------------- argument checks
+def test_bad_arguments_fail_loudly():
+    from gcn_amd.lib import CcnnError
+    params, cubes, onehot = make_problem(103, 4, 1, np.float32)
+    with pytest.raises((ValueError, TypeError)):
+        ops.mbgd_grad(dev(params), dev(cubes), dev(onehot), 2, 4, 103)          # batch runs past the data
+    with pytest.raises((ValueError, TypeError)):
+        ops.forward(dev(params.astype(np.float64)), dev(cubes), 103)            # dtype mismatch
+    with pytest.raises(CcnnError):
+        ops.forward(dev(params), dev(cubes), 5)                                 # too few bands
