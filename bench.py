@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Throughput of the Cube-CNN hot path on MI355X: fp32 minibatch training
+(forward + backward + update) in pixels/s, plus inference pixels/s.
+
+    python bench.py --gpus N --steps K --warmup W [--workload pavia_u|indian_pines|ksc] [--batch 128]
+
+One process per GPU (the driver launches N>1 through torch.distributed.run);
+data-parallel weak scaling: every rank owns 1/N of the training pixels and runs
+`--batch` samples per step, gradients are all-reduced over RCCL, every rank applies
+the identical update.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import synth  # noqa: E402  (seeded synthetic scenes)
+from gcn_amd import lib as L  # noqa: E402
+from gcn_amd import ops, prep  # noqa: E402
+
+PEAK_FP32_MATRIX_TFLOPS = 157.3     # MI355X dense f32 MFMA
+PEAK_HBM_GBS = 8000.0               # HBM3E spec
+SEED_BASE = 20240
+WORKLOAD_CONFIG = {"ksc": 2, "indian_pines": 3, "pavia_u": 4, "aviris": 5}
+
+
+def kernel_work(d, B):
+    """Algorithmic FLOPs (or bytes) per launch of each training kernel."""
+    conv = 2.0 * 171 * d.re * 20
+    fc1 = 2.0 * d.pout * 100
+    return {
+        "conv_pool_fwd": ("mfma", B * conv),
+        "fc1_partial": ("mfma", B * fc1),
+        "head": ("mfma", B * 4.0 * 1300),
+        "fc1_bwd_delta": ("mfma", B * fc1),
+        "conv_bwd": ("mfma", B * conv),
+        "grad_reduce": ("mfma", B * (fc1 + 2.0 * 1300)),
+        "update_f32_kernel": ("hbm", 3.0 * d.nparams * 4),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--workload", default="pavia_u", choices=["pavia_u", "indian_pines", "ksc"])
+    ap.add_argument("--batch", type=int, default=128, help="samples per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    L.load()
+
+    # ---- synthetic scene of the real scene's shape, prepared exactly like training() does
+    x, y, z, nl = synth.SCENES[args.workload]
+    rng = np.random.default_rng(SEED_BASE + WORKLOAD_CONFIG[args.workload])
+    labels = synth.make_labels(x, y, nl, rng)
+    scene = synth.make_scene(x, y, z, np.float32, rng)
+    di = prep.scan_labels(labels, x, y)
+    tr9, te9, onehot, test_labels = prep.build_index(labels, di, x, y)
+    prep.shuffle(tr9, onehot, SEED_BASE)
+    params_h = prep.init_params(z, np.float32)
+    d = L.dims(z)
+    B = args.batch
+    T = len(tr9)
+    slice_len = T // world
+    lo = rank * slice_len
+    nb = slice_len // B
+    assert nb >= 1, "slice smaller than one batch"
+
+    dev = torch.device("cuda", local)
+    scene_d = torch.from_numpy(scene).to(dev)
+    cubes = ops.gather(scene_d, torch.from_numpy(tr9[lo:lo + slice_len]).to(dev), x, y, z)
+    onehot_d = torch.from_numpy(np.ascontiguousarray(onehot[lo:lo + slice_len])).to(dev)
+    te_lo, te_n = rank * (len(te9) // world), len(te9) // world
+    tcubes = ops.gather(scene_d, torch.from_numpy(te9[te_lo:te_lo + te_n]).to(dev), x, y, z)
+    params = torch.from_numpy(params_h).to(dev)
+    grad = torch.empty_like(params)
+    loss_ring = torch.zeros((nb, B), dtype=torch.float64, device=dev)
+    ws = ops.Workspace(dev)
+    lr = 0.04 / world      # plain-sum update: keep the step size independent of the global batch
+
+    def step(i):
+        b = i % nb
+        ops.mbgd_grad(params, cubes, onehot_d, b * B, B, z, grad=grad, loss_values=loss_ring[b], workspace=ws)
+        if world > 1:
+            dist.all_reduce(grad)
+        ops.update(params, grad, lr, z)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    train_pps = world * B * args.steps / dt
+    assert torch.isfinite(params).all(), "training diverged"
+
+    # ---- inference over this rank's test pixels
+    fws = ops.Workspace(dev)
+    ops.forward(params, tcubes, z, want_probs=False, workspace=fws)
+    reps = max(1, int(2e6 // max(te_n, 1)))
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        ops.forward(params, tcubes, z, want_probs=False, workspace=fws)
+    fence()
+    dti = time.perf_counter() - t1
+    if world > 1:
+        t = torch.tensor([dti], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dti = t.item()
+    infer_pps = world * te_n * reps / dti
+
+    # ---- per-kernel timing of the same steps (HIP events on the launch stream)
+    roof = None
+    kernels = {}
+    if rank == 0:
+        L.profile_enable(True)
+    psteps = min(args.steps, 300)
+    for i in range(psteps):
+        step(i)
+    fence()
+    if rank == 0:
+        L.profile_enable(False)
+        rep = L.profile_report()
+        work = kernel_work(d, B)
+        for name, (ms, cnt) in rep.items():
+            if name not in work or cnt == 0:
+                continue
+            bound, units = work[name]
+            avg_s = ms / cnt * 1e-3
+            if bound == "mfma":
+                ach, peak, unit = units / avg_s / 1e12, PEAK_FP32_MATRIX_TFLOPS, "TFLOP/s"
+            else:
+                ach, peak, unit = units / avg_s / 1e9, PEAK_HBM_GBS, "GB/s"
+            kernels[name] = {"avg_us": round(avg_s * 1e6, 3), "launches": cnt, "bound": bound,
+                             "achieved": round(ach, 4), "peak": peak, "unit": unit, "frac": round(ach / peak, 5)}
+        if kernels:
+            dom = max(kernels, key=lambda k: kernels[k]["avg_us"])
+            k = kernels[dom]
+            roof = {"kernel": dom, "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"],
+                    "unit": k["unit"], "frac": k["frac"], "traffic": None, "avg_us": k["avg_us"]}
+
+    # ---- CPU baseline: the oracle's fp32 minibatch step on the host cores (rank 0, N=1 only)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle as orc
+        cubes_h = cubes[:min(slice_len, 16 * B)].cpu().numpy()
+        onehot_h = np.ascontiguousarray(onehot[lo:lo + len(cubes_h)])
+        p = params_h.copy()
+        nbh = len(cubes_h) // B
+        orc.mbgd_step(p, cubes_h, onehot_h, 0, B, z, np.float32(0.04), want_grad=False)   # warm-up
+        n_done, tc0 = 0, time.perf_counter()
+        while time.perf_counter() - tc0 < args.cpu_seconds:
+            orc.mbgd_step(p, cubes_h, onehot_h, (n_done % nbh) * B, B, z, np.float32(0.04), want_grad=False)
+            n_done += 1
+        tc = time.perf_counter() - tc0
+        cpu = {"value": round(n_done * B / tc, 1), "unit": "train pixels/s", "cores": orc.num_threads(),
+               "kind": "port", "sample": f"{n_done} fp32 MBGD steps of {B} {args.workload} pixels "
+                                         f"(oracle/ccnn_oracle.c, OpenMP over samples)"}
+
+    if rank == 0:
+        out = {
+            "metric": "train pixels/sec (fwd+bwd+update), MBGD fp32",
+            "value": round(train_pps, 1),
+            "unit": "pixels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 5),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}-shaped {x}x{y}x{z} fp32 MBGD", "batch_per_gpu": B,
+                       "global_batch": B * world, "train_pixels": T, "parallelism": f"dp{world}"},
+            "infer_pixels_per_s": round(infer_pps, 1),
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "kernels": kernels,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -6,6 +6,7 @@
 // order: the stores are one contiguous run per sample, and the nine neighbour
 // reads of a band are three short runs that neighbouring samples share in L2.
 #include "ccnn_common.h"
+#include "profile.h"
 
 namespace ccnn {
 
@@ -40,7 +41,10 @@ int gather_impl(const T *scene, const int *idx9, long n, int x, int y, int z, T 
     if ((long)x * y > 0x7fffffffL) return CCNN_E_RANGE;   // idx9 is int32
     long blocks = (n + 3) / 4;          // 4 waves per block, one sample per wave
     if (blocks > 8192) blocks = 8192;
-    gather_kernel<T><<<(int)blocks, 256, 0, st>>>(scene, idx9, n, (long)x * y, z, out);
+    {
+        ProfileScope prof_("gather_kernel", st);
+        gather_kernel<T><<<(int)blocks, 256, 0, st>>>(scene, idx9, n, (long)x * y, z, out);
+    }
     CCNN_LAUNCH_CHECK();
     return 0;
 }

@@ -11,6 +11,7 @@
 //   bp_maxpooling + bp_convolution      -> conv_bwd           (sparse over pooled maxima)
 //   update_params_row/col               -> grad_reduce (batch sums) + update
 #include "ccnn_common.h"
+#include "profile.h"
 
 namespace ccnn {
 
@@ -469,15 +470,24 @@ int forward_impl(const T *params, const T *cubes, long n, int z, T *probs, int *
     const int nch = nchunks(d.pout);
     for (long s0 = 0; s0 < n; s0 += rows) {
         const int nr = (int)((n - s0) < rows ? (n - s0) : rows);
-        conv_pool_fwd<T, FLIP><<<nr, 256, conv_smem<T>(d), st>>>(params, cubes, s0, d.cube, d.re, d.mre,
+        {
+            ProfileScope prof_("conv_pool_fwd", st);
+            conv_pool_fwd<T, FLIP><<<nr, 256, conv_smem<T>(d), st>>>(params, cubes, s0, d.cube, d.re, d.mre,
                                                                 d.off_b0, w.pool, nullptr);
+        }
         CCNN_LAUNCH_CHECK();
-        fc1_partial<T><<<dim3(nch, (nr + 15) / 16), 128, 0, st>>>(params + d.off_w1, w.pool, nr, d.pout,
+        {
+            ProfileScope prof_("fc1_partial", st);
+            fc1_partial<T><<<dim3(nch, (nr + 15) / 16), 128, 0, st>>>(params + d.off_w1, w.pool, nr, d.pout,
                                                                   w.z1part);
+        }
         CCNN_LAUNCH_CHECK();
-        head<T><<<nr, 128, 0, st>>>(params, d.off_b1, d.off_w2, d.off_b2, w.z1part, nch, nr, nullptr,
+        {
+            ProfileScope prof_("head", st);
+            head<T><<<nr, 128, 0, st>>>(params, d.off_b1, d.off_w2, d.off_b2, w.z1part, nch, nr, nullptr,
                                     nullptr, nullptr, nullptr, probs ? probs + s0 * O : nullptr,
                                     argmax ? argmax + s0 : nullptr, nullptr);
+        }
         CCNN_LAUNCH_CHECK();
     }
     return 0;
@@ -526,25 +536,43 @@ int mbgd_grad_impl(const T *params, const T *cubes, const int *onehot, long firs
     MbgdWs<T> w(ws, B, d);
     const int nch = nchunks(d.pout);
     const dim3 tiles(nch, (B + 15) / 16);
-    conv_pool_fwd<T, FLIP><<<B, 256, conv_smem<T>(d), st>>>(params, cubes, first, d.cube, d.re, d.mre,
+    {
+        ProfileScope prof_("conv_pool_fwd", st);
+        conv_pool_fwd<T, FLIP><<<B, 256, conv_smem<T>(d), st>>>(params, cubes, first, d.cube, d.re, d.mre,
                                                            d.off_b0, w.pool, w.pidx);
+    }
     CCNN_LAUNCH_CHECK();
-    fc1_partial<T><<<tiles, 128, 0, st>>>(params + d.off_w1, w.pool, B, d.pout, w.z1part);
+    {
+        ProfileScope prof_("fc1_partial", st);
+        fc1_partial<T><<<tiles, 128, 0, st>>>(params + d.off_w1, w.pool, B, d.pout, w.z1part);
+    }
     CCNN_LAUNCH_CHECK();
-    head<T><<<B, 128, 0, st>>>(params, d.off_b1, d.off_w2, d.off_b2, w.z1part, nch, B,
+    {
+        ProfileScope prof_("head", st);
+        head<T><<<B, 128, 0, st>>>(params, d.off_b1, d.off_w2, d.off_b2, w.z1part, nch, B,
                                onehot + first * O, w.a1, w.d1, w.d2, probs ? probs : w.probs, nullptr,
                                loss_values);
+    }
     CCNN_LAUNCH_CHECK();
-    fc1_bwd_delta<T><<<tiles, 256, 0, st>>>(params + d.off_w1, w.d1, w.pool, B, d.pout, w.dpool);
+    {
+        ProfileScope prof_("fc1_bwd_delta", st);
+        fc1_bwd_delta<T><<<tiles, 256, 0, st>>>(params + d.off_w1, w.d1, w.pool, B, d.pout, w.dpool);
+    }
     CCNN_LAUNCH_CHECK();
-    conv_bwd<T><<<B, 256, convbwd_smem<T>(d), st>>>(cubes, first, d.cube, d.re, d.mre, w.dpool, w.pool,
+    {
+        ProfileScope prof_("conv_bwd", st);
+        conv_bwd<T><<<B, 256, convbwd_smem<T>(d), st>>>(cubes, first, d.cube, d.re, d.mre, w.dpool, w.pool,
                                                    w.pidx, w.slab);
+    }
     CCNN_LAUNCH_CHECK();
     const int nb_w1 = (d.pout + 7) / 8;
     const int nb_w0 = (F * K + F + 127) / 128;
-    grad_reduce<T><<<nb_w1 + nb_w0 + 11 + 1, 128, 0, st>>>(B, d.pout, d.off_w1, d.off_b1, d.off_w2,
+    {
+        ProfileScope prof_("grad_reduce", st);
+        grad_reduce<T><<<nb_w1 + nb_w0 + 11 + 1, 128, 0, st>>>(B, d.pout, d.off_w1, d.off_b1, d.off_w2,
                                                            d.off_b2, w.pool, w.a1, w.d1, w.d2, w.slab,
                                                            nb_w1, nb_w0, grad);
+    }
     CCNN_LAUNCH_CHECK();
     return 0;
 }
@@ -586,7 +614,10 @@ int ccnn_count_correct(const int *argmax, const int *labels, long n, int *count,
     if (n == 0) return 0;
     long blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    count_correct_kernel<<<(int)blocks, 256, 0, st>>>(argmax, labels, n, count);
+    {
+        ProfileScope prof_("count_correct_kernel", st);
+        count_correct_kernel<<<(int)blocks, 256, 0, st>>>(argmax, labels, n, count);
+    }
     CCNN_LAUNCH_CHECK();
     return 0;
 }
@@ -618,7 +649,10 @@ int ccnn_update_f64(double *params, const double *grad, double lr, int divisor, 
 {
     if (!params || !grad || divisor <= 0 || n < 0) return CCNN_E_INVALID;
     if (n == 0) return 0;
-    update_f64_kernel<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(params, grad, lr, divisor, n);
+    {
+        ProfileScope prof_("update_f64_kernel", (hipStream_t)stream);
+        update_f64_kernel<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(params, grad, lr, divisor, n);
+    }
     CCNN_LAUNCH_CHECK();
     return 0;
 }
@@ -628,8 +662,11 @@ int ccnn_update_f32(float *params, const float *grad, float lr, int z, int freez
     ccnn_dims_t d;
     if (make_dims(z, &d) || !params || !grad) return CCNN_E_INVALID;
     const int lo = freeze_conv_bias ? d.off_b0 : 0, hi = freeze_conv_bias ? d.off_w1 : 0;
-    update_f32_kernel<<<(d.nparams + 255) / 256, 256, 0, (hipStream_t)stream>>>(params, grad, lr, d.nparams,
+    {
+        ProfileScope prof_("update_f32_kernel", (hipStream_t)stream);
+        update_f32_kernel<<<(d.nparams + 255) / 256, 256, 0, (hipStream_t)stream>>>(params, grad, lr, d.nparams,
                                                                                lo, hi);
+    }
     CCNN_LAUNCH_CHECK();
     return 0;
 }
@@ -639,8 +676,11 @@ int ccnn_update_adagrad_f64(double *params, double *rms, const double *grad, dou
 {
     if (!params || !rms || !grad || iter <= 0 || n < 0) return CCNN_E_INVALID;
     if (n == 0) return 0;
-    update_adagrad_f64_kernel<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(params, rms, grad, lr,
+    {
+        ProfileScope prof_("update_adagrad_f64_kernel", (hipStream_t)stream);
+        update_adagrad_f64_kernel<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(params, rms, grad, lr,
                                                                                       iter, n);
+    }
     CCNN_LAUNCH_CHECK();
     return 0;
 }

@@ -15,6 +15,7 @@
 //                      as the pending head update (the other WGs are still
 //                      reading W2/b2/b1 in this launch).
 #include "ccnn_common.h"
+#include "profile.h"
 
 namespace ccnn {
 
@@ -241,17 +242,26 @@ int ccnn_sgd_f64(double *params, const double *cubes, const int *onehot, long fi
     for (long i = 0; i < count; i++) {
         const long s = first + i;
         const double *cube = cubes + s * (long)d.cube;
-        sgd_fwd<<<F, 256, smem_f, st>>>(params, cube, d.cube, d.re, d.mre, d.off_b0, d.off_w1, d.off_b1,
+        {
+            ProfileScope prof_("sgd_fwd", st);
+            sgd_fwd<<<F, 256, smem_f, st>>>(params, cube, d.cube, d.re, d.mre, d.off_b0, d.off_w1, d.off_b1,
                                         d.off_w2, d.off_b2, lr, i > 0, ws);
+        }
         CCNN_LAUNCH_CHECK();
-        sgd_bwd<<<F, 256, smem_b, st>>>(params, cube, onehot + s * O, d.cube, d.re, d.mre, d.off_b0,
+        {
+            ProfileScope prof_("sgd_bwd", st);
+            sgd_bwd<<<F, 256, smem_b, st>>>(params, cube, onehot + s * O, d.cube, d.re, d.mre, d.off_b0,
                                         d.off_w1, d.off_b1, d.off_w2, d.off_b2, lr, s == 0, loss, ws);
+        }
         CCNN_LAUNCH_CHECK();
     }
     if (count > 0) {
         // flush the last sample's pending head update
-        sgd_fwd<<<F, 256, smem_f, st>>>(params, nullptr, d.cube, d.re, d.mre, d.off_b0, d.off_w1, d.off_b1,
+        {
+            ProfileScope prof_("sgd_fwd", st);
+            sgd_fwd<<<F, 256, smem_f, st>>>(params, nullptr, d.cube, d.re, d.mre, d.off_b0, d.off_w1, d.off_b1,
                                         d.off_w2, d.off_b2, lr, 1, ws);
+        }
         CCNN_LAUNCH_CHECK();
     }
     return 0;

@@ -52,6 +52,8 @@ _SIG = {
     "ccnn_host_init_params_f32": (C.c_int, [_P, C.c_int]),
     "ccnn_host_sched_init": (C.c_int, [C.POINTER(LrSched), C.c_double, C.c_int]),
     "ccnn_host_sched_step": (C.c_int, [C.POINTER(LrSched), C.c_double, C.POINTER(C.c_double)]),
+    "ccnn_profile_enable": (C.c_int, [C.c_int]),
+    "ccnn_profile_report": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
     "ccnn_host_partition": (C.c_int, [C.c_long, C.c_int, C.c_int, C.c_int, C.c_long,
                                       C.POINTER(C.c_long), C.POINTER(C.c_int)]),
 }
@@ -93,3 +95,20 @@ def dims(z):
     d = Dims()
     check(load().ccnn_get_dims(int(z), C.byref(d)), "ccnn_get_dims")
     return d
+
+
+def profile_enable(on):
+    load().ccnn_profile_enable(int(bool(on)))
+
+
+def profile_report():
+    """{kernel name: (total ms, launches)} for everything launched while timing was enabled."""
+    lib = load()
+    out = {}
+    name = C.create_string_buffer(64)
+    ms, cnt = C.c_double(), C.c_long()
+    i = 0
+    while lib.ccnn_profile_report(i, name, 64, C.byref(ms), C.byref(cnt)):
+        out[name.value.decode()] = (ms.value, cnt.value)
+        i += 1
+    return out

@@ -203,6 +203,16 @@ int ccnn_host_sched_step(ccnn_lr_sched_t *s, double epoch_loss, double *lr);
 int ccnn_host_partition(long n_train, int batch, int n_ranks, int rank, long step,
                         long *first_sample, int *sub_batch);
 
+
+/* Measurement hooks (no counterpart in the reference).  While enabled, every
+ * kernel launch of this library is bracketed by two HIP events on its own
+ * stream.  ccnn_profile_report(i, ...) returns 1 and the i-th kernel's name,
+ * summed milliseconds and launch count, 0 past the end; index 0 first waits for
+ * and folds in all launches recorded so far.  Process-wide state; meant for
+ * bench.py, leave disabled otherwise. */
+int ccnn_profile_enable(int on);
+int ccnn_profile_report(int index, char *name, int name_len, double *total_ms, long *launches);
+
 #ifdef __cplusplus
 }
 #endif
