@@ -102,10 +102,13 @@ def main():
 
     def step(i):
         b = i % nb
-        ops.mbgd_grad(params, cubes, onehot_d, b * B, B, z, grad=grad, loss_values=loss_ring[b], workspace=ws)
-        if world > 1:
+        if world == 1:
+            # gradient + update fused (nothing has to happen in between on one GPU)
+            ops.mbgd_step(params, cubes, onehot_d, b * B, B, z, lr, loss_values=loss_ring[b], workspace=ws)
+        else:
+            ops.mbgd_grad(params, cubes, onehot_d, b * B, B, z, grad=grad, loss_values=loss_ring[b], workspace=ws)
             dist.all_reduce(grad)
-        ops.update(params, grad, lr, z)
+            ops.update(params, grad, lr, z)
 
     def fence():
         if world > 1:

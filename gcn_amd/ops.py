@@ -146,6 +146,29 @@ def mbgd_grad(params, cubes, onehot, first, B, z, grad=None, loss_values=None, p
     return grad, loss_values
 
 
+def mbgd_step(params, cubes, onehot, first, B, z, lr, loss_values=None, workspace=None):
+    """Gradient and the variant's own update in one call (single GPU); params updated in place."""
+    sfx, es = _sfx(params.dtype)
+    d = _l.dims(z)
+    _req(params, params.dtype, "params", d.nparams)
+    n = cubes.numel() // d.cube
+    _req(cubes, params.dtype, "cubes", n * d.cube)
+    _req(onehot, torch.int32, "onehot", n * 13)
+    if B <= 0 or first < 0 or first + B > n:
+        raise ValueError(f"batch [{first}, {first + B}) outside [0, {n})")
+    if loss_values is None:
+        loss_values = torch.empty(B, dtype=_F64, device=params.device)
+    _req(loss_values, _F64, "loss_values")
+    if loss_values.numel() < B:
+        raise ValueError("loss_values shorter than the batch")
+    lib = _l.load()
+    ws = (workspace or Workspace(params.device)).get(lib.ccnn_mbgd_workspace_bytes(B, z, es))
+    fn = getattr(lib, f"ccnn_mbgd_step_{sfx}")
+    _l.check(fn(_ptr(params), _ptr(cubes), _ptr(onehot), first, B, z, float(lr), _ptr(loss_values), _ptr(ws),
+                ws.numel(), _stream()), f"ccnn_mbgd_step_{sfx}")
+    return loss_values
+
+
 def update(params, grad, lr, z, divisor=None, freeze_conv_bias=True):
     """fp64: params -= lr*grad/divisor.  fp32: params -= lr*grad with the conv bias
     left untouched (the fp32 reference never updates it)."""

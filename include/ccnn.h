@@ -123,6 +123,18 @@ int ccnn_mbgd_grad_f64(const double *params, const double *cubes, const int *one
                        int B, int z, double *grad, double *loss_values, double *probs,
                        void *workspace, size_t workspace_bytes, void *stream);
 
+/* ccnn_mbgd_grad + the variant's own update fused into one call (single-GPU
+ * training, where nothing has to happen between gradient and update): the batch
+ * sums are applied to params in place and no gradient is stored.
+ *   _f32: params[k] -= lr * sum, conv bias untouched   (gcn_mbgd_fp32.cu:1031-1059)
+ *   _f64: params[k] -= lr * sum / B                    (gcn_mbgd_fp64.cu:1034-1060) */
+int ccnn_mbgd_step_f32(float *params, const float *cubes, const int *onehot, long first, int B,
+                       int z, float lr, double *loss_values, void *workspace,
+                       size_t workspace_bytes, void *stream);
+int ccnn_mbgd_step_f64(double *params, const double *cubes, const int *onehot, long first, int B,
+                       int z, double lr, double *loss_values, void *workspace,
+                       size_t workspace_bytes, void *stream);
+
 /* Parameter update from a summed gradient.  Replaces update_params_row x2 +
  * update_params_col (gcn_mbgd_fp64.cu:500-557, 1034-1060) and, on several GPUs,
  * the master's update over all gathered slabs

@@ -164,6 +164,26 @@ def test_mbgd_steps_match_oracle(dtype, z, B, lr):
         assert relerr(p_gpu.cpu().numpy(), p_ref) < TOL[dtype], i0
 
 
+@pytest.mark.parametrize("dtype,z,B,lr", [(np.float64, 176, 100, 0.5), (np.float32, 103, 128, 0.04),
+                                          (np.float32, 200, 50, 0.04), (np.float64, 30, 7, 0.5)])
+def test_mbgd_fused_step_matches_oracle(dtype, z, B, lr):
+    """ccnn_mbgd_step = gradient + the variant's own update in one call."""
+    steps = 3
+    params, cubes, onehot = make_problem(z, B * steps, 17 + z, dtype)
+    p_ref = params.copy()
+    p_gpu, c_gpu, o_gpu = dev(params), dev(cubes), dev(onehot)
+    ws = ops.Workspace()
+    d = orc.dims(z)
+    for i0 in range(steps):
+        lv_ref, _, _ = orc.mbgd_step(p_ref, cubes, onehot, i0 * B, B, z, dtype(lr), want_grad=False)
+        lv = ops.mbgd_step(p_gpu, c_gpu, o_gpu, i0 * B, B, z, lr, workspace=ws)
+        assert relerr(lv.cpu().numpy(), lv_ref) < TOL[dtype], i0
+        out = p_gpu.cpu().numpy()
+        assert relerr(out, p_ref) < TOL[dtype], i0
+        if dtype == np.float32:
+            assert np.all(out[d.off_b0:d.off_w1] == 0)
+
+
 def test_adagrad_update_matches_oracle():
     rng = np.random.default_rng(1)
     n = 5000
