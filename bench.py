@@ -38,11 +38,9 @@ def kernel_work(d, B):
     conv = 2.0 * 171 * d.re * 20
     fc1 = 2.0 * d.pout * 100
     return {
-        "conv_pool_fwd": ("mfma", B * conv),
-        "fc1_partial": ("mfma", B * fc1),
-        "head": ("mfma", B * 4.0 * 1300),
-        "fc1_bwd_delta": ("mfma", B * fc1),
-        "conv_bwd": ("mfma", B * conv),
+        # conv fwd + conv bwd, FC1 fwd + delta, FC2 fwd + delta
+        "sample_fwd_bwd": ("mfma", B * (2 * conv + 2 * fc1 + 4.0 * 1300)),
+        # dW1 = pool^T d1, dW2 = a1^T d2
         "grad_reduce": ("mfma", B * (fc1 + 2.0 * 1300)),
         "update_f32_kernel": ("hbm", 3.0 * d.nparams * 4),
     }

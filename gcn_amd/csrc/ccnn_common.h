@@ -55,6 +55,15 @@ struct Carver {
     }
 };
 
+// Kernels whose dynamic LDS can exceed the 64 KB default need the limit raised once
+// per (kernel, device).
+int raise_smem_limit(const void *kernel, size_t bytes);
+template <typename Kern>
+inline int allow_smem(Kern k, size_t bytes)
+{
+    return bytes <= 64 * 1024 ? 0 : raise_smem_limit(reinterpret_cast<const void *>(k), bytes);
+}
+
 #define CCNN_LAUNCH_CHECK()                         \
     do {                                            \
         hipError_t e_ = hipGetLastError();          \

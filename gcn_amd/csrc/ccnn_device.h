@@ -1,0 +1,229 @@
+// Device-side building blocks shared by the forward (inference) and minibatch
+// training kernels: the 16x16x4 MFMA wrapper, LDS staging helpers, the conv
+// forward/backward tile loops and the reference's small reductions.
+#pragma once
+
+#include "ccnn_common.h"
+
+namespace ccnn {
+
+// ---------------------------------------------------------------------------
+// 16x16x4 MFMA wrapper.  Lane l supplies A[row l&15][k l>>4] and B[k l>>4][col l&15];
+// it receives four results in column l&15 at rows Mma<T>::row(l, 0..3).
+template <typename T>
+struct Mma;
+template <>
+struct Mma<float> {
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c)
+    {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int lane, int r) { return ((lane >> 4) << 2) + r; }
+};
+template <>
+struct Mma<double> {
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c)
+    {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + (r << 2); }
+};
+
+// LDS row strides.  A stride of 15 (mod 32) elements lets 16 lanes that walk rows
+// and the 16 lanes one element further hit distinct banks (one pair excepted); 16
+// (mod 32) does the same for lanes that walk columns of two adjacent rows.
+constexpr int LDW0 = 175;   // conv filters   [F][175], 171 taps + zero pad
+constexpr int LDW1 = 112;   // W1 chunk       [64 p][112], fc1_partial (lanes walk n)
+constexpr int LDP = 79;     // pool tile      [16 b][79]
+constexpr int LDW2 = 111;   // W1 chunk       [64 p][111], fc1_bwd_delta (lanes walk p)
+constexpr int KSTEPS0 = (K + 3) / 4;   // 43 k-steps cover the 171 taps
+
+__host__ __device__ inline int conv_mtiles(int re) { return (re + 15) >> 4; }
+__host__ __device__ inline int conv_cube_pad(int re) { return WSTEP * 16 * conv_mtiles(re) + 160; }
+__host__ __device__ inline int odd_up(int v) { return v | 1; }
+// smallest stride >= n that is 15 (mod 32)
+__host__ __device__ inline int stride15(int n) { return n + ((15 - n) % 32 + 32) % 32; }
+
+// Cooperative global -> LDS staging with U loads in flight per thread: all loads of
+// a round are issued before the first LDS store waits on them (a plain
+// load/store loop is compiled to one exposed memory round trip per element).
+// put(e, v) stores element e wherever the layout wants it.
+template <int U, int NT, typename T, typename Put>
+__device__ __forceinline__ void stage(const T *__restrict__ src, int n, int tid, Put put)
+{
+    for (int base = 0; base < n; base += U * NT) {
+        T tmp[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int e = base + u * NT + tid;
+            tmp[u] = e < n ? src[e] : T(0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int e = base + u * NT + tid;
+            if (e < n) put(e, tmp[u]);
+        }
+    }
+}
+
+// 16-byte vectors of T (float4 / double2) for aligned staging.
+template <typename T>
+struct Vec16 {
+    static constexpr int W = 16 / sizeof(T);
+    typedef T type __attribute__((ext_vector_type(16 / sizeof(T))));
+};
+template <int U, int NT, typename T, typename Put>
+__device__ __forceinline__ void stage_vec(const T *__restrict__ src, int nvec, int tid, Put put)
+{
+    typedef typename Vec16<T>::type V;
+    const V *vsrc = reinterpret_cast<const V *>(src);
+    for (int base = 0; base < nvec; base += U * NT) {
+        V tmp[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int e = base + u * NT + tid;
+            if (e < nvec) tmp[u] = vsrc[e];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int e = base + u * NT + tid;
+            if (e < nvec) put(e, tmp[u]);
+        }
+    }
+}
+
+// The reference's ceil-halving tree over 13 values (13 -> 7 -> 4 -> 2 -> 1), in
+// registers: t[i] += t[i+7] (i<6); t[i] += t[i+4] (i<3); t[i] += t[i+2] (i<2); t[0] += t[1].
+template <typename T>
+__device__ __forceinline__ T tree13(const T *v)
+{
+    T t[O];
+#pragma unroll
+    for (int i = 0; i < O; i++) t[i] = v[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) t[i] = t[i] + t[i + 7];
+#pragma unroll
+    for (int i = 0; i < 3; i++) t[i] = t[i] + t[i + 4];
+    t[0] = t[0] + t[2];
+    t[1] = t[1] + t[3];
+    return t[0] + t[1];
+}
+
+// Per-sample loss as the two MBGD references define it.
+// fp64: -sum(y log p + (1-y) log(1-p))/13          (gcn_mbgd_fp64.cu:572-594)
+__device__ __forceinline__ double sample_loss(const double *p, const int *lab)
+{
+    double tmp = 0.0;
+    for (int i = 0; i < O; i++) tmp = tmp + lab[i] * log(p[i]) + (1 - lab[i]) * log(1 - p[i]);
+    return -tmp / O;
+}
+// fp32: class-balanced logistic expression on the probabilities, float inner
+// arithmetic, double accumulators                   (gcn_mbgd_fp32.cu:578-604)
+__device__ __forceinline__ double sample_loss(const float *p, const int *lab)
+{
+    int count_pos = 0, count_neg = 0;
+    double pos = 0, neg = 0;
+    for (int i = 0; i < O; i++) {
+        const float o = p[i];
+        const int ge = (o >= 0);
+        const float term = o * (lab[i] - ge) - logf(1 + expf(o - 2 * o * ge));
+        if (lab[i] == 1) {
+            count_pos++;
+            pos -= term;
+        } else if (lab[i] == 0) {
+            count_neg++;
+            neg -= term;
+        }
+    }
+    return (pos * count_neg / O) * 1 + (neg * count_pos / O);
+}
+
+
+// ---------------------------------------------------------------------------
+// Conv forward tiles for one LDS-resident sample: a0[f][t] = tanh*(sum_k wl[f][k] cube[18 t + k] + b0[f]).
+// The [re x 171] x [171 x 20] product is ceil(re/16) x 2 MFMA tiles; wave w takes
+// position tiles w, w+4, ... with both filter halves, so each A fragment feeds two
+// MFMAs.  A comes straight from the cube (window t starts at 18 t: no im2col).
+// wl is [32][LDW0] with rows 20..31 and taps 171..174 zero; cube is zero-padded to
+// conv_cube_pad(re); a0 rows have stride lda.
+template <typename T>
+__device__ __forceinline__ void conv_fwd_tiles(const T *cube, const T *wl, T *a0, int lda, int re,
+                                               T bias0, T bias1, int lane, int wave)
+{
+    const int col = lane & 15, kq = lane >> 4;
+    const int f1 = 16 + col;
+    const int mt = conv_mtiles(re);
+    for (int tile = wave; tile < mt; tile += 4) {
+        const T *ap = cube + WSTEP * (tile * 16 + col) + kq;
+        const T *bp0 = wl + col * LDW0 + kq;
+        const T *bp1 = wl + f1 * LDW0 + kq;
+        typename Mma<T>::acc_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+        int s = 0;
+        for (; s + 4 <= KSTEPS0; s += 4) {   // operands of four k-steps in flight
+            T a[4], b0[4], b1[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                a[u] = ap[4 * (s + u)];
+                b0[u] = bp0[4 * (s + u)];
+                b1[u] = bp1[4 * (s + u)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                acc0 = Mma<T>::mma(a[u], b0[u], acc0);
+                acc1 = Mma<T>::mma(a[u], b1[u], acc1);
+            }
+        }
+        for (; s < KSTEPS0; s++) {
+            const T a = ap[4 * s];
+            acc0 = Mma<T>::mma(a, bp0[4 * s], acc0);
+            acc1 = Mma<T>::mma(a, bp1[4 * s], acc1);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int t = tile * 16 + Mma<T>::row(lane, r);
+            if (t < re) {
+                a0[col * lda + t] = act(acc0[r] + bias0);
+                if (f1 < F) a0[f1 * lda + t] = act(acc1[r] + bias1);
+            }
+        }
+    }
+}
+
+// Stages the 20 x 171 filters into wl[32][LDW0] (zero rows/taps included).  The
+// fp32 reference walks the filter backwards in the forward pass only
+// (gcn_mbgd_fp32.cu:241-243): FLIP stores tap k at 170-k.  Needs a barrier after.
+template <typename T, bool FLIP>
+__device__ __forceinline__ void stage_filters(const T *__restrict__ w0, T *wl, int tid)
+{
+    for (int e = tid; e < 32 * LDW0; e += 256) wl[e] = 0;
+    __syncthreads();
+    stage<7, 256>(w0, F * K, tid, [&](int e, T v) {
+        const int f = e / K, k = e - f * K;
+        wl[f * LDW0 + (FLIP ? K - 1 - k : k)] = v;
+    });
+}
+
+// Max-pool (window 2, clipped, strict '<' so the first maximum wins,
+// gcn_mbgd_fp64.cu:237-268) of a0[F][lda]; put(o, value, winning position).
+template <typename T, typename Put>
+__device__ __forceinline__ void pool_rows(const T *a0, int lda, int re, int mre, int tid, Put put)
+{
+    for (int o = tid; o < F * mre; o += 256) {
+        const int f = o / mre, m = o - f * mre;
+        const int t = 2 * m;
+        T best = a0[f * lda + t];
+        int bt = t;
+        if (t + 1 < re) {
+            const T vn = a0[f * lda + t + 1];
+            if (best < vn) {
+                best = vn;
+                bt = t + 1;
+            }
+        }
+        put(o, best, bt);
+    }
+}
+
+}  // namespace ccnn

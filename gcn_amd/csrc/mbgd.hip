@@ -1,0 +1,534 @@
+// Minibatch gradient (and fused update) of the Cube CNN in two launches per step.
+//
+// The reference runs 9 launches per sample on 100 streams and keeps per-sample
+// gradient slabs [B x params] (gcn_mbgd_fp64.cu:931-1064).  Here:
+//
+//   sample_fwd_bwd  one workgroup per sample does the whole per-sample chain with
+//                   the cube resident in LDS: conv (MFMA) -> tanh -> pool -> FC1 ->
+//                   FC2 -> softmax/loss -> delta2 -> delta1 -> delta at the pooled
+//                   features -> bp_maxpooling scatter -> conv gradient (MFMA).
+//                   It leaves pool, a1, delta1, delta2 and its conv-gradient tile
+//                   [F*K + F] in the workspace.
+//   grad_reduce     sums over the batch in the flat parameter layout:
+//                   dW1 = pool^T delta1 as an MFMA product with K = batch, the rest
+//                   as column sums; optionally applies the update in the same pass.
+//
+// Only what differs between samples is per-sample; nothing of size [B x |W1|] exists.
+// A launch boundary costs about as much as one of these kernels' whole run, so the
+// per-sample chain is fused rather than batched layer by layer; FC1 (100 x Pout) is a
+// matrix-vector product per sample here, read through L2.
+#include "ccnn_device.h"
+#include "profile.h"
+
+namespace ccnn {
+
+__host__ __device__ inline int up4(int v) { return (v + 3) & ~3; }
+
+// LDS carve of sample_fwd_bwd, in elements of T (every region a multiple of 4
+// elements so 16-byte accesses stay aligned), then the int region.
+struct FusedLayout {
+    int cube, wl, a0, pl, dp, a1, d1, es, ps, d2, total;   // element offsets / count
+    int ldd, ks;
+    size_t px_off, bytes;
+};
+
+template <typename T>
+__host__ __device__ inline FusedLayout fused_layout(int re, int mre)
+{
+    FusedLayout L;
+    const int pout = F * mre;
+    L.ks = (re + 3) >> 2;
+    L.ldd = stride15(4 * L.ks);
+    const int wl_len = 32 * (L.ldd > LDW0 ? L.ldd : LDW0);   // filters, later the scattered deltas
+    const int a0_len = F * odd_up(re) > 8 * H ? F * odd_up(re) : 8 * H;   // conv outputs, later FC1 partial sums
+    int o = 0;
+    L.cube = o; o += up4(conv_cube_pad(re));
+    L.wl = o;   o += up4(wl_len);
+    L.a0 = o;   o += up4(a0_len);
+    L.pl = o;   o += up4(pout);
+    L.dp = o;   o += up4(pout);
+    L.a1 = o;   o += up4(H);
+    L.d1 = o;   o += up4(H);
+    L.es = o;   o += 16;
+    L.ps = o;   o += 16;
+    L.d2 = o;   o += 16;
+    L.total = o;
+    L.px_off = (size_t)o * sizeof(T);
+    L.bytes = L.px_off + (size_t)up4(pout) * sizeof(int);
+    return L;
+}
+
+// Conv weight gradient of one sample as an MFMA product:
+// dW0[f][tap] = sum_t delta[f][t] cube[18 t + tap] / re  ([20 x re] x [re x 171]),
+// 2 filter tiles x 11 tap tiles, wave w owns tap tiles w, w+4, w+8.
+// delta is [32][ldd] (rows 20..31 zero), cube zero-padded; out = [F][K].
+template <typename T>
+__device__ __forceinline__ void conv_bwd_tiles(const T *cube, const T *delta, int ldd, int ks, int re,
+                                               T *__restrict__ out, int lane, int wave)
+{
+    const int col = lane & 15, kq = lane >> 4;
+    const T *ap0 = delta + col * ldd + kq;
+    const T *ap1 = delta + (16 + col) * ldd + kq;
+    const bool t2 = wave + 8 < 11;   // 171 taps = 11 tiles
+    const T *bp0 = cube + WSTEP * kq + wave * 16 + col;
+    const T *bp1 = bp0 + 64;
+    const T *bp2 = bp0 + (t2 ? 128 : 0);
+    typename Mma<T>::acc_t c00 = {0, 0, 0, 0}, c01 = c00, c02 = c00, c10 = c00, c11 = c00, c12 = c00;
+    auto kstep2 = [&](int s, int n) {   // n (1 or 2) k-steps: all operands first, then the MFMAs
+        T a0[2], a1[2], b0[2], b1[2], b2[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            if (u < n) {
+                a0[u] = ap0[4 * (s + u)];
+                a1[u] = ap1[4 * (s + u)];
+                b0[u] = bp0[4 * (s + u) * WSTEP];
+                b1[u] = bp1[4 * (s + u) * WSTEP];
+                b2[u] = bp2[4 * (s + u) * WSTEP];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            if (u < n) {
+                c00 = Mma<T>::mma(a0[u], b0[u], c00);
+                c10 = Mma<T>::mma(a1[u], b0[u], c10);
+                c01 = Mma<T>::mma(a0[u], b1[u], c01);
+                c11 = Mma<T>::mma(a1[u], b1[u], c11);
+                if (t2) {
+                    c02 = Mma<T>::mma(a0[u], b2[u], c02);
+                    c12 = Mma<T>::mma(a1[u], b2[u], c12);
+                }
+            }
+        }
+    };
+    int s = 0;
+    for (; s + 2 <= ks; s += 2) kstep2(s, 2);
+    if (s < ks) kstep2(s, 1);
+    auto emit = [&](const typename Mma<T>::acc_t &acc, int ftile, int ttile) {
+        const int tap = ttile * 16 + col;
+        if (tap >= K) return;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int f = ftile * 16 + Mma<T>::row(lane, r);
+            if (f < F) out[f * K + tap] = acc[r] / re;   // gcn_mbgd_fp64.cu:491
+        }
+    };
+    emit(c00, 0, wave);
+    emit(c10, 1, wave);
+    emit(c01, 0, wave + 4);
+    emit(c11, 1, wave + 4);
+    if (t2) {
+        emit(c02, 0, wave + 8);
+        emit(c12, 1, wave + 8);
+    }
+}
+
+// ---------------------------------------------------------------------------
+template <typename T, bool FLIP>
+__global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ params,
+                                                      const T *__restrict__ cubes,
+                                                      const int *__restrict__ onehot, long first,
+                                                      ccnn_dims_t d, T *__restrict__ pool_g,
+                                                      T *__restrict__ a1_g, T *__restrict__ d1_g,
+                                                      T *__restrict__ d2_g, T *__restrict__ probs_g,
+                                                      double *__restrict__ loss_values,
+                                                      T *__restrict__ slab)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const FusedLayout L = fused_layout<T>(d.re, d.mre);
+    T *base = reinterpret_cast<T *>(smem);
+    T *cube = base + L.cube, *wl = base + L.wl, *a0 = base + L.a0, *pl = base + L.pl, *dp = base + L.dp;
+    T *a1s = base + L.a1, *d1s = base + L.d1, *es = base + L.es, *ps = base + L.ps, *d2s = base + L.d2;
+    int *px = reinterpret_cast<int *>(smem + L.px_off);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15;
+    const int re = d.re, mre = d.mre, pout = d.pout;
+    const int lda = odd_up(re);
+    const long row = blockIdx.x;
+    const int *lab = onehot + (first + row) * O;
+
+    // ---- forward: conv + tanh + pool ------------------------------------------------
+    for (int e = d.cube + tid; e < conv_cube_pad(re); e += 256) cube[e] = 0;
+    stage_filters<T, FLIP>(params + d.off_w0, wl, tid);
+    stage<8, 256>(cubes + (first + row) * (long)d.cube, d.cube, tid, [&](int e, T v) { cube[e] = v; });
+    const T bias0 = params[d.off_b0 + col];
+    const T bias1 = 16 + col < F ? params[d.off_b0 + 16 + col] : T(0);
+    __syncthreads();
+    conv_fwd_tiles<T>(cube, wl, a0, lda, re, bias0, bias1, lane, wave);
+    __syncthreads();
+    {
+        T *dst = pool_g + row * pout;
+        pool_rows<T>(a0, lda, re, mre, tid, [&](int o, T v, int bt) {
+            pl[o] = v;
+            px[o] = bt;
+            dst[o] = v;
+        });
+    }
+    __syncthreads();
+
+    // ---- FC1 forward: z1[n] = sum_p pool[p] W1[n + 100 p] ---------------------------
+    // 16-byte vectors along n; QL lanes per W1 row (25 or 50 of them active), G row groups.
+    typedef typename Vec16<T>::type V;
+    constexpr int VW = Vec16<T>::W;
+    constexpr int NQ = H / VW;
+    constexpr int QL = NQ <= 32 ? 32 : 64;
+    constexpr int G = 256 / QL;
+    const int q = tid & (QL - 1), g = tid / QL;
+    const bool qv = q < NQ;
+    const V *W1v = reinterpret_cast<const V *>(params + d.off_w1);
+    T *z1p = a0;   // [G][H] partial sums (the conv outputs are dead)
+    {
+        V acc = {};
+        for (int pb = 0; pb < pout; pb += G * 8) {
+            V w[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int p = pb + u * G + g;
+                if (qv && p < pout) w[u] = W1v[(long)p * NQ + q];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int p = pb + u * G + g;
+                if (qv && p < pout) acc += w[u] * pl[p];
+            }
+        }
+        if (qv) reinterpret_cast<V *>(z1p + g * H)[q] = acc;
+    }
+    __syncthreads();
+    T a = 0;
+    if (tid < H) {
+        T zsum = 0;
+#pragma unroll
+        for (int gg = 0; gg < G; gg++) zsum = zsum + z1p[gg * H + tid];
+        a = 2 / (1 + 1 / rexp((zsum + params[d.off_b1 + tid]) * 2)) - 1;   // gcn_mbgd_fp64.cu:302
+        a1s[tid] = a;
+        a1_g[row * H + tid] = a;
+    }
+    __syncthreads();
+
+    // ---- output layer, softmax, loss, delta2, delta1 ---------------------------------
+    const T *W2 = params + d.off_w2;
+    {
+        const int o8 = tid >> 3, j8 = tid & 7;   // 13 outputs x 8 partial sums
+        T mid = 0;
+        if (o8 < O)
+            for (int i = j8; i < H; i += 8) mid = mid + W2[o8 + i * O] * a1s[i];
+        mid += __shfl_xor(mid, 4);
+        mid += __shfl_xor(mid, 2);
+        mid += __shfl_xor(mid, 1);
+        if (o8 < O && j8 == 0) es[o8] = rexp(mid + params[d.off_b2 + o8]);
+    }
+    __syncthreads();
+    if (tid < O) {
+        const T p = es[tid] / tree13(es);
+        ps[tid] = p;
+        if (probs_g) probs_g[row * O + tid] = p;
+        const T dv = (p - lab[tid]) / O;   // gcn_mbgd_fp64.cu:352
+        d2s[tid] = dv;
+        d2_g[row * O + tid] = dv;
+    }
+    // the filters are dead: clear their region for the scattered deltas
+    for (int e = tid; e < 32 * L.ldd; e += 256) wl[e] = 0;
+    __syncthreads();
+    if (tid == 255) loss_values[row] = sample_loss(ps, lab);
+    if (tid < H) {
+        // bp_fully_connect(out -> hidden), gcn_mbgd_fp64.cu:416-434: 13-wide tree
+        T prod[O];
+#pragma unroll
+        for (int o = 0; o < O; o++) prod[o] = W2[o + tid * O] * d2s[o];
+        const T dv = tree13(prod) * (1 + a) * (1 - a);
+        d1s[tid] = dv;
+        d1_g[row * H + tid] = dv;
+    }
+    __syncthreads();
+
+    // ---- delta at the pooled features + bp_maxpooling scatter -----------------------
+    // dpool[p] = (sum_n W1[n + 100 p] d1[n]) (1 + pool)(1 - pool), gcn_mbgd_fp64.cu:416-434, 450-452
+    {
+        T *delta = wl;
+        V d1v = {};
+        if (qv) d1v = reinterpret_cast<const V *>(d1s)[q];
+        for (int pb = 0; pb < pout; pb += G * 8) {
+            V w[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int p = pb + u * G + g;
+                if (qv && p < pout) w[u] = W1v[(long)p * NQ + q];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int p = pb + u * G + g;
+                T part = 0;
+                if (qv && p < pout) {
+#pragma unroll
+                    for (int j = 0; j < VW; j++) part = part + w[u][j] * d1v[j];
+                }
+#pragma unroll
+                for (int off = QL / 2; off > 0; off >>= 1) part += __shfl_xor(part, off);
+                if (q == 0 && p < pout) {
+                    const T pv = pl[p];
+                    const T dv = part * (1 + pv) * (1 - pv);
+                    dp[p] = dv;
+                    delta[(p / mre) * L.ldd + px[p]] = dv;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- conv gradient tile of this sample -------------------------------------------
+    T *out = slab + row * (long)(F * K + F);
+    conv_bwd_tiles<T>(cube, wl, L.ldd, L.ks, re, out, lane, wave);
+    if (tid < F) {
+        // bias path: at a winner the conv output equals the pooled value, so the
+        // reference's second tanh' (gcn_mbgd_fp64.cu:487-488) needs only pl
+        T mid1 = 0;
+        for (int m = 0; m < mre; m++) {
+            const T pv = pl[tid * mre + m];
+            mid1 = mid1 + dp[tid * mre + m] * (1 + pv) * (1 - pv);
+        }
+        out[F * K + tid] = mid1 / re;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Batch sums of the per-sample gradients, written in the flat parameter layout
+// (update_params_row/col, gcn_mbgd_fp64.cu:513-517, 546-550).  With an UpdateRule
+// the update is applied in the same pass instead of storing the gradient.
+//   blocks [0, nb_w1)  dW1[n + 100 p] = sum_b pool[b][p] d1[b][n]: one 16-wide p tile
+//                      per block, one neuron tile per wave (7 of the 8), K = batch (MFMA)
+//   then column sums, 64 columns x 8 row groups per block, groups added in order:
+//     nb_w0 blocks     dW0 | db0 = sum_b slab[b][.]
+//     nb_w2 blocks     dW2[o + 13 n] = sum_b a1[b][n] d2[b][o]
+//     2 blocks         db1 = sum_b d1        1 block   db2 = sum_b d2
+constexpr int GR_THREADS = 512;
+
+template <typename T>
+struct UpdateRule {
+    T *params;       // null: store the gradient
+    T lr;
+    int divisor;     // fp64: w -= lr*g/divisor (gcn_mbgd_fp64.cu:519); 0: w -= lr*g (gcn_mbgd_fp32.cu:529)
+    int frozen_lo, frozen_hi;
+    __device__ __forceinline__ void apply(T *grad, int k, T g) const
+    {
+        if (!params) {
+            grad[k] = g;
+        } else if (!(k >= frozen_lo && k < frozen_hi)) {
+            params[k] = divisor ? params[k] - lr * g / divisor : params[k] - lr * g;
+        }
+    }
+};
+
+// Sum over rows b = rg, rg+8, ... of term(b), 16 loads in flight; then over the 8 row groups.
+template <typename T, typename Term>
+__device__ __forceinline__ T colsum8(int B, int rg, int c, T *red, Term term)
+{
+    T acc = 0;
+    for (int b0 = rg; b0 < B; b0 += 8 * 16) {
+        T v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int b = b0 + 8 * u;
+            v[u] = b < B ? term(b) : T(0);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++) acc = acc + v[u];
+    }
+    red[rg * 64 + c] = acc;
+    __syncthreads();
+    T tot = 0;
+    if (rg == 0) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) tot = tot + red[r * 64 + c];
+    }
+    return tot;
+}
+
+template <typename T>
+__global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int off_w1, int off_b1,
+                                                          int off_w2, int off_b2,
+                                                          const T *__restrict__ pool,
+                                                          const T *__restrict__ a1,
+                                                          const T *__restrict__ d1,
+                                                          const T *__restrict__ d2,
+                                                          const T *__restrict__ slab, int nb_w1,
+                                                          int nb_w0, int nb_w2, T *__restrict__ grad,
+                                                          UpdateRule<T> upd)
+{
+    __shared__ T red[8 * 64];
+    const int tid = threadIdx.x;
+    int blk = blockIdx.x;
+    if (blk < nb_w1) {
+        const int lane = tid & 63, wave = tid >> 6;
+        if (wave >= 7) return;
+        const int col = lane & 15, kq = lane >> 4;
+        const int p0 = blk * 16, n0 = wave * 16;
+        const bool pv = p0 + col < pout, nv = n0 + col < H;
+        const T *ap = pool + min(p0 + col, pout - 1);   // clamped: loads stay in bounds, masked below
+        const T *bp = d1 + min(n0 + col, H - 1);
+        typename Mma<T>::acc_t acc = {0, 0, 0, 0};
+        const int ks = (B + 3) >> 2;
+        for (int s = 0; s < ks; s += 16) {   // sixteen k-steps of operands in flight
+            T a[16], w[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const int b = min(4 * (s + u) + kq, B - 1);
+                a[u] = ap[(long)b * pout];
+                w[u] = bp[(long)b * H];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const bool bv = 4 * (s + u) + kq < B;
+                acc = Mma<T>::mma((bv && pv) ? a[u] : T(0), (bv && nv) ? w[u] : T(0), acc);
+            }
+        }
+        if (nv) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int p = p0 + Mma<T>::row(lane, r);
+                if (p < pout) upd.apply(grad, off_w1 + n0 + col + H * p, acc[r]);
+            }
+        }
+        return;
+    }
+    blk -= nb_w1;
+    const int c = tid & 63, rg = tid >> 6;
+    if (blk < nb_w0) {
+        const int k = min(blk * 64 + c, F * K + F - 1);
+        const T tot = colsum8<T>(B, rg, c, red, [&](int b) { return slab[(long)b * (F * K + F) + k]; });
+        if (rg == 0 && blk * 64 + c < F * K + F) upd.apply(grad, k, tot);   // slab layout = W0 | b0 = params[0..)
+        return;
+    }
+    blk -= nb_w0;
+    if (blk < nb_w2) {
+        const int k = min(blk * 64 + c, H * O - 1);   // k = o + 13 n
+        const int nn = k / O, o = k - nn * O;
+        const T tot = colsum8<T>(B, rg, c, red, [&](int b) { return a1[(long)b * H + nn] * d2[(long)b * O + o]; });
+        if (rg == 0 && blk * 64 + c < H * O) upd.apply(grad, off_w2 + k, tot);
+        return;
+    }
+    blk -= nb_w2;
+    if (blk < 2) {
+        const int n = min(blk * 64 + c, H - 1);
+        const T tot = colsum8<T>(B, rg, c, red, [&](int b) { return d1[(long)b * H + n]; });
+        if (rg == 0 && blk * 64 + c < H) upd.apply(grad, off_b1 + n, tot);
+        return;
+    }
+    {
+        const int o = min(c, O - 1);
+        const T tot = colsum8<T>(B, rg, c, red, [&](int b) { return d2[(long)b * O + o]; });
+        if (rg == 0 && c < O) upd.apply(grad, off_b2 + o, tot);
+    }
+}
+
+// ---------------------------------------------------------------------------
+template <typename T>
+struct MbgdWs {
+    T *pool, *a1, *d1, *d2, *slab, *probs;
+    static size_t bytes(int B, const ccnn_dims_t &d)
+    {
+        size_t b = 0;
+        b += align_up((size_t)B * d.pout * sizeof(T));          // pool
+        b += 2 * align_up((size_t)B * H * sizeof(T));           // a1, d1
+        b += 2 * align_up((size_t)B * O * sizeof(T));           // d2, probs
+        b += align_up((size_t)B * (F * K + F) * sizeof(T));     // per-sample conv gradient tiles
+        return b;
+    }
+    MbgdWs(void *ws, int B, const ccnn_dims_t &d)
+    {
+        Carver c(ws);
+        pool = c.take<T>((size_t)B * d.pout);
+        a1 = c.take<T>((size_t)B * H);
+        d1 = c.take<T>((size_t)B * H);
+        d2 = c.take<T>((size_t)B * O);
+        probs = c.take<T>((size_t)B * O);
+        slab = c.take<T>((size_t)B * (F * K + F));
+    }
+};
+
+// grad != null: store the batch-summed gradient.  grad == null: apply `upd` in place.
+template <typename T, bool FLIP>
+int mbgd_impl(const T *params, const T *cubes, const int *onehot, long first, int B, int z, T *grad,
+              UpdateRule<T> upd, double *loss_values, T *probs, void *ws, size_t ws_bytes,
+              hipStream_t st)
+{
+    ccnn_dims_t d;
+    if (make_dims(z, &d)) return CCNN_E_INVALID;
+    if (!params || !cubes || !onehot || !loss_values || !ws || B <= 0 || first < 0) return CCNN_E_INVALID;
+    if (!grad && !upd.params) return CCNN_E_INVALID;
+    if (ws_bytes < MbgdWs<T>::bytes(B, d)) return CCNN_E_WORKSPACE;
+    MbgdWs<T> w(ws, B, d);
+    const FusedLayout L = fused_layout<T>(d.re, d.mre);
+    if (int e = allow_smem(sample_fwd_bwd<T, FLIP>, L.bytes)) return e;
+    {
+        ProfileScope prof_("sample_fwd_bwd", st);
+        sample_fwd_bwd<T, FLIP><<<B, 256, L.bytes, st>>>(params, cubes, onehot, first, d, w.pool, w.a1, w.d1,
+                                                        w.d2, probs, loss_values, w.slab);
+    }
+    CCNN_LAUNCH_CHECK();
+    const int nb_w1 = (d.pout + 15) / 16;
+    const int nb_w0 = (F * K + F + 63) / 64;
+    const int nb_w2 = (H * O + 63) / 64;
+    {
+        ProfileScope prof_("grad_reduce", st);
+        grad_reduce<T><<<nb_w1 + nb_w0 + nb_w2 + 3, GR_THREADS, 0, st>>>(B, d.pout, d.off_w1, d.off_b1,
+                                                                         d.off_w2, d.off_b2, w.pool, w.a1,
+                                                                         w.d1, w.d2, w.slab, nb_w1, nb_w0,
+                                                                         nb_w2, grad, upd);
+    }
+    CCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace ccnn
+
+using namespace ccnn;
+
+extern "C" {
+
+size_t ccnn_mbgd_workspace_bytes(int B, int z, int elem_size)
+{
+    ccnn_dims_t d;
+    if (make_dims(z, &d) || B <= 0) return 0;
+    return elem_size == 8 ? MbgdWs<double>::bytes(B, d) : MbgdWs<float>::bytes(B, d);
+}
+
+int ccnn_mbgd_grad_f32(const float *params, const float *cubes, const int *onehot, long first, int B,
+                       int z, float *grad, double *loss_values, float *probs, void *workspace,
+                       size_t workspace_bytes, void *stream)
+{
+    if (!grad) return CCNN_E_INVALID;
+    return mbgd_impl<float, true>(params, cubes, onehot, first, B, z, grad, UpdateRule<float>{}, loss_values,
+                                  probs, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int ccnn_mbgd_grad_f64(const double *params, const double *cubes, const int *onehot, long first, int B,
+                       int z, double *grad, double *loss_values, double *probs, void *workspace,
+                       size_t workspace_bytes, void *stream)
+{
+    if (!grad) return CCNN_E_INVALID;
+    return mbgd_impl<double, false>(params, cubes, onehot, first, B, z, grad, UpdateRule<double>{},
+                                    loss_values, probs, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int ccnn_mbgd_step_f32(float *params, const float *cubes, const int *onehot, long first, int B, int z,
+                       float lr, double *loss_values, void *workspace, size_t workspace_bytes, void *stream)
+{
+    ccnn_dims_t d;
+    if (make_dims(z, &d) || !params) return CCNN_E_INVALID;
+    // plain-sum update, conv bias frozen (gcn_mbgd_fp32.cu:529, 561, 1052-1059)
+    UpdateRule<float> upd{params, lr, 0, d.off_b0, d.off_w1};
+    return mbgd_impl<float, true>(params, cubes, onehot, first, B, z, nullptr, upd, loss_values, nullptr,
+                                  workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int ccnn_mbgd_step_f64(double *params, const double *cubes, const int *onehot, long first, int B, int z,
+                       double lr, double *loss_values, void *workspace, size_t workspace_bytes, void *stream)
+{
+    ccnn_dims_t d;
+    if (make_dims(z, &d) || !params) return CCNN_E_INVALID;
+    UpdateRule<double> upd{params, lr, B, 0, 0};   // mean over the batch (gcn_mbgd_fp64.cu:519)
+    return mbgd_impl<double, false>(params, cubes, onehot, first, B, z, nullptr, upd, loss_values, nullptr,
+                                    workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+}  // extern "C"
