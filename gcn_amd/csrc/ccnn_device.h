@@ -57,8 +57,9 @@ __device__ __forceinline__ void stage(const T *__restrict__ src, int n, int tid,
         T tmp[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
+            // clamped, unconditional: a guarded load becomes a branch plus a full wait per element
             const int e = base + u * NT + tid;
-            tmp[u] = e < n ? src[e] : T(0);
+            tmp[u] = src[e < n ? e : n - 1];
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -84,7 +85,7 @@ __device__ __forceinline__ void stage_vec(const T *__restrict__ src, int nvec, i
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int e = base + u * NT + tid;
-            if (e < nvec) tmp[u] = vsrc[e];
+            tmp[u] = vsrc[e < nvec ? e : nvec - 1];
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -111,35 +112,92 @@ __device__ __forceinline__ T tree13(const T *v)
     return t[0] + t[1];
 }
 
-// Per-sample loss as the two MBGD references define it.
+// Per-sample loss as the two MBGD references define it, split so that the 13
+// per-class terms (the exp/log work) are computed by 13 lanes and only the cheap
+// ordered accumulation is serial.
 // fp64: -sum(y log p + (1-y) log(1-p))/13          (gcn_mbgd_fp64.cu:572-594)
-__device__ __forceinline__ double sample_loss(const double *p, const int *lab)
+__device__ __forceinline__ void loss_terms(double p, int lab, double *ta, double *tb)
+{
+    *ta = lab * log(p);
+    *tb = (1 - lab) * log(1 - p);
+}
+__device__ __forceinline__ double loss_sum(const double *ta, const double *tb, const int *lab)
 {
     double tmp = 0.0;
-    for (int i = 0; i < O; i++) tmp = tmp + lab[i] * log(p[i]) + (1 - lab[i]) * log(1 - p[i]);
+    for (int i = 0; i < O; i++) tmp = tmp + ta[i] + tb[i];
     return -tmp / O;
 }
 // fp32: class-balanced logistic expression on the probabilities, float inner
 // arithmetic, double accumulators                   (gcn_mbgd_fp32.cu:578-604)
-__device__ __forceinline__ double sample_loss(const float *p, const int *lab)
+__device__ __forceinline__ void loss_terms(float o, int lab, float *ta, float *tb)
+{
+    const int ge = (o >= 0);
+    *ta = o * (lab - ge) - logf(1 + expf(o - 2 * o * ge));
+    *tb = 0;
+}
+__device__ __forceinline__ double loss_sum(const float *ta, const float *tb, const int *lab)
 {
     int count_pos = 0, count_neg = 0;
     double pos = 0, neg = 0;
     for (int i = 0; i < O; i++) {
-        const float o = p[i];
-        const int ge = (o >= 0);
-        const float term = o * (lab[i] - ge) - logf(1 + expf(o - 2 * o * ge));
         if (lab[i] == 1) {
             count_pos++;
-            pos -= term;
+            pos -= ta[i];
         } else if (lab[i] == 0) {
             count_neg++;
-            neg -= term;
+            neg -= ta[i];
         }
     }
     return (pos * count_neg / O) * 1 + (neg * count_pos / O);
 }
 
+// Sum of 16 per-lane values over the QL (32 or 64) lanes of a group with ~1 shuffle
+// per value instead of log2(QL): at each step a lane keeps half of its values and
+// trades the other half with its partner, so the sums end up scattered: the lane
+// returns the complete sum of value index reduce_scatter_index<QL>(lane) (lanes that
+// share an index hold the same sum).
+template <int QL>
+__device__ __forceinline__ int reduce_scatter_index(int lane)
+{
+    return QL == 32 ? (lane >> 1) & 15 : (lane >> 2) & 15;
+}
+template <int QL, typename T>
+__device__ __forceinline__ T reduce_scatter16(T (&v)[16], int lane)
+{
+    static_assert(QL == 32 || QL == 64, "group of 32 or 64 lanes");
+    {
+        const bool hi = lane & (QL / 2);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const T keep = hi ? v[i + 8] : v[i], send = hi ? v[i] : v[i + 8];
+            v[i] = keep + __shfl_xor(send, QL / 2);
+        }
+    }
+    {
+        const bool hi = lane & (QL / 4);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const T keep = hi ? v[i + 4] : v[i], send = hi ? v[i] : v[i + 4];
+            v[i] = keep + __shfl_xor(send, QL / 4);
+        }
+    }
+    {
+        const bool hi = lane & (QL / 8);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const T keep = hi ? v[i + 2] : v[i], send = hi ? v[i] : v[i + 2];
+            v[i] = keep + __shfl_xor(send, QL / 8);
+        }
+    }
+    {
+        const bool hi = lane & (QL / 16);
+        const T keep = hi ? v[1] : v[0], send = hi ? v[0] : v[1];
+        v[0] = keep + __shfl_xor(send, QL / 16);
+    }
+#pragma unroll
+    for (int off = QL / 32; off > 0; off >>= 1) v[0] += __shfl_xor(v[0], off);
+    return v[0];
+}
 
 // ---------------------------------------------------------------------------
 // Conv forward tiles for one LDS-resident sample: a0[f][t] = tanh*(sum_k wl[f][k] cube[18 t + k] + b0[f]).

@@ -111,7 +111,8 @@ __global__ __launch_bounds__(256) void fc1_partial(const T *__restrict__ W1,
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int e = u * 256 + tid, b = e >> 6, p = e & 63;
-            tmp[u] = (b < nb && p < pmax) ? pool[(long)(r0 + b) * pout + p0 + p] : T(0);
+            const T x = pool[(long)(r0 + min(b, nb - 1)) * pout + p0 + min(p, pmax - 1)];   // clamped load
+            tmp[u] = (b < nb && p < pmax) ? x : T(0);
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -232,7 +233,11 @@ __global__ __launch_bounds__(128) void head(const T *__restrict__ params, int of
                     }
                 argmax[b] = idx;
             }
-            if (onehot && loss_values) loss_values[b] = sample_loss(ps, onehot + b * O);
+            if (onehot && loss_values) {
+                T ta[O], tb[O];
+                for (int i = 0; i < O; i++) loss_terms(ps[i], onehot[b * O + i], &ta[i], &tb[i]);
+                loss_values[b] = loss_sum(ta, tb, onehot + b * O);
+            }
         }
         if (onehot && n < H) {
             // bp_fully_connect(out -> hidden), gcn_mbgd_fp64.cu:416-434: 13-wide tree

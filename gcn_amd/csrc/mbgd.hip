@@ -20,6 +20,10 @@
 #include "ccnn_device.h"
 #include "profile.h"
 
+#ifndef CCNN_STOP_PHASE
+#define CCNN_STOP_PHASE 0   // diagnostic builds only: end sample_fwd_bwd after phase N
+#endif
+
 namespace ccnn {
 
 __host__ __device__ inline int up4(int v) { return (v + 3) & ~3; }
@@ -27,7 +31,7 @@ __host__ __device__ inline int up4(int v) { return (v + 3) & ~3; }
 // LDS carve of sample_fwd_bwd, in elements of T (every region a multiple of 4
 // elements so 16-byte accesses stay aligned), then the int region.
 struct FusedLayout {
-    int cube, wl, a0, pl, dp, a1, d1, es, ps, d2, total;   // element offsets / count
+    int cube, wl, a0, pl, dp, a1, d1, es, ps, d2, lta, ltb, total;   // element offsets / count
     int ldd, ks;
     size_t px_off, bytes;
 };
@@ -52,6 +56,8 @@ __host__ __device__ inline FusedLayout fused_layout(int re, int mre)
     L.es = o;   o += 16;
     L.ps = o;   o += 16;
     L.d2 = o;   o += 16;
+    L.lta = o;  o += 16;
+    L.ltb = o;  o += 16;
     L.total = o;
     L.px_off = (size_t)o * sizeof(T);
     L.bytes = L.px_off + (size_t)up4(pout) * sizeof(int);
@@ -138,6 +144,7 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
     T *base = reinterpret_cast<T *>(smem);
     T *cube = base + L.cube, *wl = base + L.wl, *a0 = base + L.a0, *pl = base + L.pl, *dp = base + L.dp;
     T *a1s = base + L.a1, *d1s = base + L.d1, *es = base + L.es, *ps = base + L.ps, *d2s = base + L.d2;
+    T *lta = base + L.lta, *ltb = base + L.ltb;
     int *px = reinterpret_cast<int *>(smem + L.px_off);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15;
@@ -147,14 +154,50 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
     const int *lab = onehot + (first + row) * O;
 
     // ---- forward: conv + tanh + pool ------------------------------------------------
-    for (int e = d.cube + tid; e < conv_cube_pad(re); e += 256) cube[e] = 0;
-    stage_filters<T, FLIP>(params + d.off_w0, wl, tid);
-    stage<8, 256>(cubes + (first + row) * (long)d.cube, d.cube, tid, [&](int e, T v) { cube[e] = v; });
+    // Issue every global load this phase needs (filters, cube, and the small output-layer
+    // operands used much later) before touching LDS, so one memory round trip covers them.
+    constexpr int NWREG = (F * K + 255) / 256;
+    T wreg[NWREG];
+#pragma unroll
+    for (int u = 0; u < NWREG; u++) {
+        const int e = u * 256 + tid;
+        wreg[u] = params[d.off_w0 + (e < F * K ? e : F * K - 1)];   // clamped: loads stay unconditional
+    }
+    const T *W2 = params + d.off_w2;
+    const int o8 = tid >> 3, j8 = tid & 7;   // output layer: 13 outputs x 8 partial sums
+    T w2f[O], w2b[O];
+#pragma unroll
+    for (int k = 0; k < O; k++) {
+        const int i = min(j8 + 8 * k, H - 1);   // hidden unit of the k-th partial product
+        w2f[k] = W2[min(o8, O - 1) + i * O];
+        w2b[k] = W2[k + min(tid, H - 1) * O];
+    }
+    const T b1v = params[d.off_b1 + min(tid, H - 1)];
+    const T b2v = params[d.off_b2 + min(o8, O - 1)];
     const T bias0 = params[d.off_b0 + col];
-    const T bias1 = 16 + col < F ? params[d.off_b0 + 16 + col] : T(0);
+    const T bias1 = params[d.off_b0 + min(16 + col, F - 1)];
+    for (int e = d.cube + tid; e < conv_cube_pad(re); e += 256) cube[e] = 0;
+    for (int e = tid; e < 32 * LDW0; e += 256) wl[e] = 0;
+    stage<8, 256>(cubes + (first + row) * (long)d.cube, d.cube, tid, [&](int e, T v) { cube[e] = v; });
     __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NWREG; u++) {
+        const int e = u * 256 + tid;
+        if (e < F * K) {
+            const int f = e / K, k = e - f * K;
+            // the fp32 reference walks the filter backwards in the forward pass (gcn_mbgd_fp32.cu:241-243)
+            wl[f * LDW0 + (FLIP ? K - 1 - k : k)] = wreg[u];
+        }
+    }
+    __syncthreads();
+#if CCNN_STOP_PHASE == 1
+    return;
+#endif
     conv_fwd_tiles<T>(cube, wl, a0, lda, re, bias0, bias1, lane, wave);
     __syncthreads();
+#if CCNN_STOP_PHASE == 2
+    return;
+#endif
     {
         T *dst = pool_g + row * pout;
         pool_rows<T>(a0, lda, re, mre, tid, [&](int o, T v, int bt) {
@@ -174,48 +217,60 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
     constexpr int G = 256 / QL;
     const int q = tid & (QL - 1), g = tid / QL;
     const bool qv = q < NQ;
+    const int qc = qv ? q : NQ - 1;
     const V *W1v = reinterpret_cast<const V *>(params + d.off_w1);
     T *z1p = a0;   // [G][H] partial sums (the conv outputs are dead)
+    // Every workgroup reads all of W1; start each at a different row so that at any moment
+    // the 128 workgroups pull from different L2 channels instead of queueing on the same lines.
+    const int rot = (int)((row * 37) % pout);
+    constexpr int UF = 16;   // W1 rows in flight per thread
     {
         V acc = {};
-        for (int pb = 0; pb < pout; pb += G * 8) {
-            V w[8];
+        for (int pb = 0; pb < pout; pb += G * UF) {
+            V w[UF];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int p = pb + u * G + g;
-                if (qv && p < pout) w[u] = W1v[(long)p * NQ + q];
+            for (int u = 0; u < UF; u++) {
+                int p = min(pb + u * G + g, pout - 1) + rot;   // clamped: loads stay unconditional
+                p = p >= pout ? p - pout : p;
+                w[u] = W1v[(long)p * NQ + qc];
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int p = pb + u * G + g;
-                if (qv && p < pout) acc += w[u] * pl[p];
+            for (int u = 0; u < UF; u++) {
+                int p = min(pb + u * G + g, pout - 1) + rot;
+                p = p >= pout ? p - pout : p;
+                const T x = (qv && pb + u * G + g < pout) ? pl[p] : T(0);
+                acc += w[u] * x;
             }
         }
         if (qv) reinterpret_cast<V *>(z1p + g * H)[q] = acc;
     }
     __syncthreads();
+#if CCNN_STOP_PHASE == 3
+    return;
+#endif
     T a = 0;
     if (tid < H) {
         T zsum = 0;
 #pragma unroll
         for (int gg = 0; gg < G; gg++) zsum = zsum + z1p[gg * H + tid];
-        a = 2 / (1 + 1 / rexp((zsum + params[d.off_b1 + tid]) * 2)) - 1;   // gcn_mbgd_fp64.cu:302
+        a = 2 / (1 + 1 / rexp((zsum + b1v) * 2)) - 1;   // gcn_mbgd_fp64.cu:302
         a1s[tid] = a;
         a1_g[row * H + tid] = a;
     }
     __syncthreads();
 
     // ---- output layer, softmax, loss, delta2, delta1 ---------------------------------
-    const T *W2 = params + d.off_w2;
     {
-        const int o8 = tid >> 3, j8 = tid & 7;   // 13 outputs x 8 partial sums
         T mid = 0;
-        if (o8 < O)
-            for (int i = j8; i < H; i += 8) mid = mid + W2[o8 + i * O] * a1s[i];
+#pragma unroll
+        for (int k = 0; k < O; k++) {
+            const int i = j8 + 8 * k;
+            if (i < H) mid = mid + w2f[k] * a1s[i];
+        }
         mid += __shfl_xor(mid, 4);
         mid += __shfl_xor(mid, 2);
         mid += __shfl_xor(mid, 1);
-        if (o8 < O && j8 == 0) es[o8] = rexp(mid + params[d.off_b2 + o8]);
+        if (o8 < O && j8 == 0) es[o8] = rexp(mid + b2v);
     }
     __syncthreads();
     if (tid < O) {
@@ -225,21 +280,25 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
         const T dv = (p - lab[tid]) / O;   // gcn_mbgd_fp64.cu:352
         d2s[tid] = dv;
         d2_g[row * O + tid] = dv;
+        loss_terms(p, lab[tid], &lta[tid], &ltb[tid]);
     }
     // the filters are dead: clear their region for the scattered deltas
     for (int e = tid; e < 32 * L.ldd; e += 256) wl[e] = 0;
     __syncthreads();
-    if (tid == 255) loss_values[row] = sample_loss(ps, lab);
+    if (tid == 255) loss_values[row] = loss_sum(lta, ltb, lab);
     if (tid < H) {
         // bp_fully_connect(out -> hidden), gcn_mbgd_fp64.cu:416-434: 13-wide tree
         T prod[O];
 #pragma unroll
-        for (int o = 0; o < O; o++) prod[o] = W2[o + tid * O] * d2s[o];
+        for (int o = 0; o < O; o++) prod[o] = w2b[o] * d2s[o];
         const T dv = tree13(prod) * (1 + a) * (1 - a);
         d1s[tid] = dv;
         d1_g[row * H + tid] = dv;
     }
     __syncthreads();
+#if CCNN_STOP_PHASE == 4
+    return;
+#endif
 
     // ---- delta at the pooled features + bp_maxpooling scatter -----------------------
     // dpool[p] = (sum_n W1[n + 100 p] d1[n]) (1 + pool)(1 - pool), gcn_mbgd_fp64.cu:416-434, 450-452
@@ -247,33 +306,40 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
         T *delta = wl;
         V d1v = {};
         if (qv) d1v = reinterpret_cast<const V *>(d1s)[q];
-        for (int pb = 0; pb < pout; pb += G * 8) {
-            V w[8];
+        static_assert(UF == 16, "reduce_scatter16 handles 16 rows per round");
+        const int ru = reduce_scatter_index<QL>(q);          // the row of the round this lane ends up owning
+        const bool writer = (q & (QL / 16 - 1)) == 0;        // one lane per owned row stores it
+        for (int pb = 0; pb < pout; pb += G * UF) {
+            V w[UF];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int p = pb + u * G + g;
-                if (qv && p < pout) w[u] = W1v[(long)p * NQ + q];
+            for (int u = 0; u < UF; u++) {
+                int p = min(pb + u * G + g, pout - 1) + rot;
+                p = p >= pout ? p - pout : p;
+                w[u] = W1v[(long)p * NQ + qc];
             }
+            T part[UF];   // d1v is zero in the lanes past the row's end
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int p = pb + u * G + g;
-                T part = 0;
-                if (qv && p < pout) {
+            for (int u = 0; u < UF; u++) {
+                part[u] = 0;
 #pragma unroll
-                    for (int j = 0; j < VW; j++) part = part + w[u][j] * d1v[j];
-                }
-#pragma unroll
-                for (int off = QL / 2; off > 0; off >>= 1) part += __shfl_xor(part, off);
-                if (q == 0 && p < pout) {
-                    const T pv = pl[p];
-                    const T dv = part * (1 + pv) * (1 - pv);
-                    dp[p] = dv;
-                    delta[(p / mre) * L.ldd + px[p]] = dv;
-                }
+                for (int j = 0; j < VW; j++) part[u] = part[u] + w[u][j] * d1v[j];
+            }
+            const T tot = reduce_scatter16<QL>(part, q);
+            const int pi = pb + ru * G + g;
+            if (writer && pi < pout) {
+                int p = pi + rot;
+                p = p >= pout ? p - pout : p;
+                const T pv = pl[p];
+                const T dv = tot * (1 + pv) * (1 - pv);
+                dp[p] = dv;
+                delta[(p / mre) * L.ldd + px[p]] = dv;
             }
         }
     }
     __syncthreads();
+#if CCNN_STOP_PHASE == 5
+    return;
+#endif
 
     // ---- conv gradient tile of this sample -------------------------------------------
     T *out = slab + row * (long)(F * K + F);
@@ -328,7 +394,8 @@ __device__ __forceinline__ T colsum8(int B, int rg, int c, T *red, Term term)
 #pragma unroll
         for (int u = 0; u < 16; u++) {
             const int b = b0 + 8 * u;
-            v[u] = b < B ? term(b) : T(0);
+            const T x = term(b < B ? b : B - 1);   // clamped load, masked value
+            v[u] = b < B ? x : T(0);
         }
 #pragma unroll
         for (int u = 0; u < 16; u++) acc = acc + v[u];

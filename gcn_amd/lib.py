@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libccnn_hip.so")
+LIB_PATH = os.environ.get("CCNN_LIB_PATH") or os.path.join(_HERE, "lib", "libccnn_hip.so")
 
 FILTERS, COV_LEN, STRIDE, POOL_LEN, HIDDEN, CLASSES, PER_LAYER, FILTER_SIZE = 20, 19, 2, 2, 100, 13, 9, 171
 

@@ -1,0 +1,18 @@
+"""Times ccnn_mbgd_step for one library build (diagnostic; pick the build with CCNN_LIB_PATH)."""
+import sys, os, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gcn_amd import ops, prep, lib as L
+z, B = int(sys.argv[1]) if len(sys.argv) > 1 else 103, 128
+d = L.dims(z)
+rng = np.random.default_rng(0)
+cubes = torch.from_numpy(rng.random((B * 8, 9 * z)).astype(np.float32)).cuda()
+onehot = np.zeros((B * 8, 13), dtype=np.int32); onehot[np.arange(B * 8), rng.integers(0, 13, B * 8)] = 1
+onehot = torch.from_numpy(onehot).cuda()
+import ctypes; ctypes.CDLL(None).srand(1)
+params = torch.from_numpy(prep.init_params(z, np.float32)).cuda()
+ws = ops.Workspace(); lv = torch.zeros(B, dtype=torch.float64, device="cuda")
+for i in range(50): ops.mbgd_step(params, cubes, onehot, (i % 8) * B, B, z, 0.0, loss_values=lv, workspace=ws)
+torch.cuda.synchronize(); t0 = time.perf_counter(); n = 500
+for i in range(n): ops.mbgd_step(params, cubes, onehot, (i % 8) * B, B, z, 0.0, loss_values=lv, workspace=ws)
+torch.cuda.synchronize(); print(os.environ.get("CCNN_LIB_PATH", "default"), f"{(time.perf_counter() - t0) / n * 1e6:.1f} us/step")
