@@ -1,0 +1,525 @@
+// `gcn` -- drop-in command line of the reference trainers on top of libccnn_hip.
+//
+//   gcn DATASET.mat device_id                  single GPU  (gcn_sgd_fp64.cu:996-1045,
+//                                               gcn_mbgd_fp64.cu:1244-1296, gcn_mbgd_fp32.cu:1222-1274)
+//   gcn DATASET.mat device_num master_dev_id   multi GPU   (hyper_version_mGPU_MBGD.cu:1331-1388)
+//
+// The reference compiles one trainer per binary; here the trainer is picked with
+// --variant=sgd_fp64|mbgd_fp64|mbgd_fp32 (default mbgd_fp32, what the reference's
+// shipped bin/gcn was built from); the four-argument form is the fp64 multi-GPU
+// trainer.  Options (all before the positional arguments):
+//   --variant=V  --seed=N (default: time, like the reference)  --epochs=N (300)
+//   --batch=N (100)  --model=PATH (load weights instead of initialising)
+//   --infer (skip training; needs --model)
+//   --mat-info=FILE, --mat-rewrite=SRC:DST   MAT-file utilities, no GPU needed
+// stdout keeps the reference's lines and spacing so tools/run.sh's field cuts work.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <string>
+#include <vector>
+
+#include "../../include/ccnn.h"
+#include "matio.h"
+
+// error_util.h:10-33 convention: message with file:line on stderr, non-zero exit
+#define CK(x)                                                                                    \
+    do {                                                                                         \
+        int e_ = (int)(x);                                                                       \
+        if (e_ != 0) {                                                                           \
+            fprintf(stderr, "%s:%d: %s\n", __FILE__, __LINE__, ccnn_error_string(e_));           \
+            exit(EXIT_FAILURE);                                                                  \
+        }                                                                                        \
+    } while (0)
+#define NCK(x)                                                                                   \
+    do {                                                                                         \
+        ncclResult_t r_ = (x);                                                                   \
+        if (r_ != ncclSuccess) {                                                                 \
+            fprintf(stderr, "%s:%d: RCCL: %s\n", __FILE__, __LINE__, ncclGetErrorString(r_));    \
+            exit(EXIT_FAILURE);                                                                  \
+        }                                                                                        \
+    } while (0)
+
+namespace {
+
+typedef std::chrono::steady_clock Clock;
+double secs(Clock::time_point a) { return std::chrono::duration<double>(Clock::now() - a).count(); }
+
+struct Options {
+    std::string variant = "mbgd_fp32", model;
+    long seed = -1;
+    int epochs = 300, batch = 100;
+    bool infer = false;
+    std::vector<std::string> pos;
+};
+
+struct Variant {
+    const char *tag;       // text inside "[Cube CNN training with ...]"
+    bool sgd, f32;
+    double lr, min_err, fifo;
+    const char *names[6];  // model.mat variable names
+    const char *model_path;
+};
+const Variant kSgd = {"SGD algo", true, false, 0.008, 0.0003, 1.0,
+                      {"filters", "conv_bias", "fulconnect_weights", "fulconnect_bias", "output_weights", "output_bias"},
+                      "model.mat"};                                      // gcn_sgd_fp64.cu:20-22, 901-931
+const Variant kMbgd64 = {"MBGD algo", false, false, 0.5, 0.0001, 1.0,
+                         {"filters", "bias0", "omega1", "bias1", "omega2", "bias2"}, "model/model.mat"};   // gcn_mbgd_fp64.cu:20-23
+const Variant kMbgd32 = {"MBGD algo", false, true, 0.04, 0.001, 100.0,
+                         {"filters", "bias0", "omega1", "bias1", "omega2", "bias2"}, "model/model.mat"};   // gcn_mbgd_fp32.cu:21-24
+const Variant kMgpu = {"MBGD algo", false, false, 0.5, 0.001, 1.0,
+                       {"filters", "bias0", "omega1", "bias1", "omega2", "bias2"}, "model/model.mat"};     // hyper_version_mGPU_MBGD.cu:20-23
+
+template <typename T>
+T *dmalloc(size_t n)
+{
+    void *p = nullptr;
+    CK(hipMalloc(&p, (n ? n : 1) * sizeof(T)));
+    return static_cast<T *>(p);
+}
+template <typename T>
+T *to_device(const std::vector<T> &h)
+{
+    T *d = dmalloc<T>(h.size());
+    if (!h.empty()) CK(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return d;
+}
+
+// Accepts the reference's three naming schemes for the six tensors.
+bool load_model(const std::string &path, const ccnn_dims_t &d, std::vector<double> &params)
+{
+    static const char *alias[6][3] = {{"filters", "kernel", nullptr},
+                                      {"bias0", "conv_bias", nullptr},
+                                      {"omega1", "fulconnect_weights", nullptr},
+                                      {"bias1", "fulconnect_bias", nullptr},
+                                      {"omega2", "output_weights", nullptr},
+                                      {"bias2", "output_bias", nullptr}};
+    const int off[7] = {d.off_w0, d.off_b0, d.off_w1, d.off_b1, d.off_w2, d.off_b2, d.nparams};
+    std::vector<matio::Array> arrs;
+    std::string err;
+    if (!matio::read(path, {}, arrs, err)) {
+        fprintf(stderr, "%s\n", err.c_str());
+        return false;
+    }
+    params.assign(d.nparams, 0.0);
+    for (int t = 0; t < 6; t++) {
+        const matio::Array *found = nullptr;
+        for (auto &a : arrs)
+            for (int k = 0; alias[t][k]; k++)
+                if (a.name == alias[t][k]) found = &a;
+        const size_t want = (size_t)(off[t + 1] - off[t]);
+        if (!found || found->numel() != want) {
+            fprintf(stderr, "model '%s': tensor %s missing or of the wrong size (need %zu values)\n", path.c_str(),
+                    alias[t][0], want);
+            return false;
+        }
+        for (size_t i = 0; i < want; i++)
+            params[off[t] + i] = found->is_single ? (double)found->f32[i] : found->f64[i];
+    }
+    return true;
+}
+
+void save_model(const Variant &v, const ccnn_dims_t &d, const std::vector<double> &params, const std::vector<double> &logloss)
+{
+    if (strchr(v.model_path, '/')) mkdir("model", 0777);
+    std::vector<matio::DoubleMatrix> vars = {
+        {v.names[0], (size_t)CCNN_FILTER_SIZE, (size_t)CCNN_FILTERS, params.data() + d.off_w0},
+        {v.names[1], (size_t)CCNN_FILTERS, 1, params.data() + d.off_b0},
+        {v.names[2], (size_t)CCNN_HIDDEN, (size_t)d.pout, params.data() + d.off_w1},
+        {v.names[3], (size_t)CCNN_HIDDEN, 1, params.data() + d.off_b1},
+        {v.names[4], (size_t)CCNN_CLASSES, (size_t)CCNN_HIDDEN, params.data() + d.off_w2},
+        {v.names[5], (size_t)CCNN_CLASSES, 1, params.data() + d.off_b2},
+        {"loss", logloss.size(), 1, logloss.data()},
+    };
+    std::string err;
+    if (!matio::write(v.model_path, vars, err)) fprintf(stderr, "warning: %s\n", err.c_str());
+}
+
+struct Samples {
+    int n_train = 0, n_test = 0;
+    std::vector<int> train_idx9, test_idx9, onehot, test_labels;
+};
+
+Samples build_samples(const std::vector<double> &labels, int x, int y, unsigned seed)
+{
+    Samples s;
+    std::vector<int> data_index((size_t)x * y);
+    int n = 0;
+    CK(ccnn_host_scan_labels(labels.data(), x, y, data_index.data(), &n));
+    if (n <= 0) {
+        fprintf(stderr, "no labelled pixels in the dataset\n");
+        exit(EXIT_FAILURE);
+    }
+    CK(ccnn_host_split_sizes(n, &s.n_train, &s.n_test));
+    s.train_idx9.resize((size_t)s.n_train * 9);
+    s.test_idx9.resize((size_t)s.n_test * 9);
+    s.onehot.resize((size_t)s.n_train * CCNN_CLASSES);
+    s.test_labels.resize(s.n_test);
+    CK(ccnn_host_build_index(labels.data(), data_index.data(), n, x, y, s.train_idx9.data(), s.test_idx9.data(),
+                             s.onehot.data(), s.test_labels.data()));
+    CK(ccnn_host_shuffle(s.train_idx9.data(), s.onehot.data(), s.n_train, seed));
+    return s;
+}
+
+// Everything one device holds.
+template <typename T>
+struct Device {
+    int id = 0;
+    hipStream_t st = nullptr;
+    T *cubes = nullptr, *params = nullptr, *grad = nullptr;
+    int *onehot = nullptr;
+    double *loss = nullptr;
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    long n_local = 0;
+};
+
+template <typename T>
+int gather_on(const T *scene, const int *idx, long n, int x, int y, int z, T *out, hipStream_t st);
+template <>
+int gather_on<float>(const float *s, const int *i, long n, int x, int y, int z, float *o, hipStream_t st)
+{
+    return ccnn_gather_f32(s, i, n, x, y, z, o, st);
+}
+template <>
+int gather_on<double>(const double *s, const int *i, long n, int x, int y, int z, double *o, hipStream_t st)
+{
+    return ccnn_gather_f64(s, i, n, x, y, z, o, st);
+}
+
+template <typename T>
+double run(const Options &opt, const Variant &v, const matio::Array &scene_a, const std::vector<double> &labels, int x,
+           int y, int z, const std::vector<int> &devices)
+{
+    const int nd = (int)devices.size();
+    const bool multi = opt.pos.size() == 3;
+    Clock::time_point t0 = Clock::now();
+    ccnn_dims_t d;
+    CK(ccnn_get_dims(z, &d));
+    const unsigned seed = opt.seed >= 0 ? (unsigned)opt.seed : (unsigned)time(NULL);
+    Samples s = build_samples(labels, x, y, seed);
+
+    // scene in the trainer's precision (the fp32 reference reads a `single` DataSet, the others `double`)
+    std::vector<T> scene((size_t)x * y * z);
+    for (size_t i = 0; i < scene.size(); i++) scene[i] = scene_a.is_single ? (T)scene_a.f32[i] : (T)scene_a.f64[i];
+
+    // weights: libc rand() continues from the shuffle, in the reference's draw order
+    const int B = opt.batch;
+    std::vector<double> params_h(d.nparams);
+    if (!opt.model.empty()) {
+        if (!load_model(opt.model, d, params_h)) exit(EXIT_FAILURE);
+    } else if (v.f32) {
+        std::vector<float> p(d.nparams);
+        CK(ccnn_host_init_params_f32(p.data(), z));
+        std::copy(p.begin(), p.end(), params_h.begin());
+    } else {
+        CK(ccnn_host_init_params_f64(params_h.data(), z, v.sgd ? d.pout : (long)d.pout * B));
+    }
+    std::vector<T> params_t(params_h.begin(), params_h.end());
+
+    // gather on the first device (the reference gathers on the master, hyper_version_mGPU_MBGD.cu:856-857)
+    CK(hipSetDevice(devices[0]));
+    T *scene_d = to_device(scene);
+    int *tr_idx_d = to_device(s.train_idx9), *te_idx_d = to_device(s.test_idx9);
+    T *train_d = dmalloc<T>((size_t)s.n_train * d.cube), *test_d = dmalloc<T>((size_t)s.n_test * d.cube);
+    CK(gather_on<T>(scene_d, tr_idx_d, s.n_train, x, y, z, train_d, nullptr));
+    CK(gather_on<T>(scene_d, te_idx_d, s.n_test, x, y, z, test_d, nullptr));
+    CK(hipDeviceSynchronize());
+    fprintf(stdout,
+            "[Samples prepared with %d Nearest-Neighbor-Pixels Strategy] Proportion of Training Samples: %d%%  Execution "
+            "time: %.3f sec\n",
+            8, 80, secs(t0));
+    CK(hipFree(scene_d));
+    CK(hipFree(tr_idx_d));
+    CK(hipFree(te_idx_d));
+
+    // per-device state; device k owns samples [k*floor(T/n), (k+1)*floor(T/n))
+    const long slice = nd > 1 ? s.n_train / nd : s.n_train;
+    const int sub_b = v.sgd ? 1 : B / nd;
+    const long batch_num = v.sgd ? 0 : s.n_train / B;
+    std::vector<Device<T>> dev(nd);
+    for (int k = 0; k < nd; k++) {
+        Device<T> &D = dev[k];
+        D.id = devices[k];
+        CK(hipSetDevice(D.id));
+        CK(hipStreamCreate(&D.st));
+        D.n_local = slice;
+        if (k == 0) {
+            D.cubes = train_d;
+            D.onehot = to_device(s.onehot);
+        } else {
+            D.cubes = dmalloc<T>((size_t)slice * d.cube);
+            CK(hipMemcpyPeer(D.cubes, D.id, train_d + (size_t)k * slice * d.cube, devices[0],
+                             (size_t)slice * d.cube * sizeof(T)));
+            std::vector<int> oh(s.onehot.begin() + (size_t)k * slice * CCNN_CLASSES,
+                                s.onehot.begin() + (size_t)(k + 1) * slice * CCNN_CLASSES);
+            D.onehot = to_device(oh);
+        }
+        D.params = to_device(params_t);
+        D.grad = dmalloc<T>(d.nparams);
+        D.loss = dmalloc<double>(std::max<long>(batch_num, 1) * std::max(sub_b, 1));
+        D.ws_bytes = v.sgd ? ccnn_sgd_workspace_bytes(z) : ccnn_mbgd_workspace_bytes(sub_b, z, (int)sizeof(T));
+        CK(hipMalloc(&D.ws, D.ws_bytes));
+    }
+    std::vector<ncclComm_t> comms(nd);
+    if (nd > 1) NCK(ncclCommInitAll(comms.data(), nd, devices.data()));
+
+    std::vector<double> logloss(300, 0.0);
+    char head[96];
+    if (v.sgd) snprintf(head, sizeof(head), "[Cube CNN training with SGD algo");
+    else snprintf(head, sizeof(head), "[Cube CNN training with MBGD algo.  BatchSize = %d", B);
+    double lr = v.lr;
+    Clock::time_point t_train = Clock::now();
+    if (!opt.infer) {
+        if (!v.sgd && (sub_b <= 0 || batch_num * sub_b > slice)) {
+            fprintf(stderr, "batch size %d does not fit %d device(s) with %d training samples\n", B, nd, s.n_train);
+            exit(EXIT_FAILURE);
+        }
+        ccnn_lr_sched_t sched;
+        CK(ccnn_host_sched_init(&sched, v.fifo, v.f32));
+        fprintf(stdout, "%s] lr = %lf\n", head, lr);
+        std::vector<double> loss_h((size_t)std::max<long>(batch_num, 1) * std::max(sub_b, 1));
+        for (int iter = 0; iter < opt.epochs; iter++) {
+            Clock::time_point t_it = Clock::now();
+            double single_rate = 0;
+            if (v.sgd) {
+                Device<T> &D = dev[0];
+                CK(ccnn_sgd_f64((double *)D.params, (const double *)D.cubes, D.onehot, 0, s.n_train, z, lr, D.loss,
+                                D.ws, D.ws_bytes, D.st));
+                double l = 0;
+                CK(hipMemcpyAsync(&l, D.loss, sizeof(double), hipMemcpyDeviceToHost, D.st));
+                CK(hipStreamSynchronize(D.st));
+                single_rate = l / s.n_train;
+                if (iter < 300) logloss[iter] = single_rate;
+                if (single_rate < v.min_err) break;   // before printing and scheduling (gcn_sgd_fp64.cu:860-861)
+            } else {
+                for (long i0 = 0; i0 < batch_num; i0++) {
+                    for (int k = 0; k < nd; k++) {
+                        Device<T> &D = dev[k];
+                        if (nd > 1) CK(hipSetDevice(D.id));
+                        double *lv = D.loss + i0 * sub_b;
+                        if (nd == 1) {
+                            if (v.f32)
+                                CK(ccnn_mbgd_step_f32((float *)D.params, (const float *)D.cubes, D.onehot, i0 * sub_b,
+                                                      sub_b, z, (float)lr, lv, D.ws, D.ws_bytes, D.st));
+                            else
+                                CK(ccnn_mbgd_step_f64((double *)D.params, (const double *)D.cubes, D.onehot, i0 * sub_b,
+                                                      sub_b, z, lr, lv, D.ws, D.ws_bytes, D.st));
+                        } else {
+                            CK(ccnn_mbgd_grad_f64((const double *)D.params, (const double *)D.cubes, D.onehot,
+                                                  i0 * sub_b, sub_b, z, (double *)D.grad, lv, nullptr, D.ws,
+                                                  D.ws_bytes, D.st));
+                        }
+                    }
+                    if (nd > 1) {
+                        // replaces weight broadcast + slab gather + master update
+                        // (hyper_version_mGPU_MBGD.cu:962-978, 1093-1171)
+                        NCK(ncclGroupStart());
+                        for (int k = 0; k < nd; k++)
+                            NCK(ncclAllReduce(dev[k].grad, dev[k].grad, d.nparams, ncclDouble, ncclSum, comms[k], dev[k].st));
+                        NCK(ncclGroupEnd());
+                        for (int k = 0; k < nd; k++) {
+                            CK(hipSetDevice(dev[k].id));
+                            CK(ccnn_update_f64((double *)dev[k].params, (const double *)dev[k].grad, lr, B, d.nparams,
+                                               dev[k].st));
+                        }
+                    }
+                }
+                // one D2H per device per epoch; host adds the per-sample losses in order
+                float loss32 = 0;
+                double loss64 = 0;
+                for (int k = 0; k < nd; k++) {
+                    CK(hipSetDevice(dev[k].id));
+                    CK(hipMemcpyAsync(loss_h.data(), dev[k].loss, sizeof(double) * batch_num * sub_b,
+                                      hipMemcpyDeviceToHost, dev[k].st));
+                    CK(hipStreamSynchronize(dev[k].st));
+                    for (long j = 0; j < batch_num * sub_b; j++) {
+                        if (v.f32) loss32 = loss32 + loss_h[j];   // `float loss` (gcn_mbgd_fp32.cu:882, 1027)
+                        else loss64 = loss64 + loss_h[j];
+                    }
+                }
+                single_rate = (v.f32 ? (double)loss32 : loss64) / s.n_train;
+                if (iter < 300) logloss[iter] = single_rate;
+            }
+            char str[50];
+            snprintf(str, sizeof(str), "%d,", iter + 1);
+            if (v.sgd)
+                fprintf(stdout, "[Cube CNN training with SGD algo. Execution time: %.3f sec] Iteration %-4s loss = %lf;\n",
+                        secs(t_it), str, single_rate);
+            else
+                fprintf(stdout, "%s  Execution time: %.3f sec] Iteration %-4s loss = %lf;\n", head, secs(t_it), str,
+                        single_rate);
+            if (ccnn_host_sched_step(&sched, single_rate, &lr) == 1) fprintf(stdout, "%s] lr = %lf\n", head, lr);
+            if (!v.sgd && single_rate < v.min_err) break;
+        }
+        if (v.sgd) fprintf(stdout, "[Cube CNN training with SGD algo] Completed! Global Execution time is %.3f sec\n", secs(t_train));
+        else fprintf(stdout, "%s] Completed! Global Exesution time is %.3f sec\n", head, secs(t_train));
+
+        CK(hipSetDevice(dev[0].id));
+        CK(hipMemcpy(params_t.data(), dev[0].params, sizeof(T) * d.nparams, hipMemcpyDeviceToHost));
+        std::copy(params_t.begin(), params_t.end(), params_h.begin());
+        if (!multi) save_model(v, d, params_h, logloss);   // the multi-GPU reference saves nothing (:1214-1252)
+    }
+
+    // test on the first device
+    Clock::time_point t_test = Clock::now();
+    CK(hipSetDevice(dev[0].id));
+    int *argmax_d = dmalloc<int>(s.n_test), *count_d = dmalloc<int>(1), *tl_d = to_device(s.test_labels);
+    const size_t fws_bytes = ccnn_forward_workspace_bytes(s.n_test, z, (int)sizeof(T));
+    void *fws = nullptr;
+    CK(hipMalloc(&fws, fws_bytes ? fws_bytes : 1));
+    if (v.f32) CK(ccnn_forward_f32((const float *)dev[0].params, (const float *)test_d, s.n_test, z, nullptr, argmax_d, fws, fws_bytes, dev[0].st));
+    else CK(ccnn_forward_f64((const double *)dev[0].params, (const double *)test_d, s.n_test, z, nullptr, argmax_d, fws, fws_bytes, dev[0].st));
+    CK(ccnn_count_correct(argmax_d, tl_d, s.n_test, count_d, dev[0].st));
+    int right = 0;
+    CK(hipMemcpyAsync(&right, count_d, sizeof(int), hipMemcpyDeviceToHost, dev[0].st));
+    CK(hipStreamSynchronize(dev[0].st));
+    fprintf(stdout, "[Cube CNN testing] Execution time is %.3f sec. ", secs(t_test));
+    if (nd > 1)
+        for (auto c : comms) ncclCommDestroy(c);
+    return s.n_test ? (double)right / s.n_test : 0.0;
+}
+
+// File utilities that need no GPU: list a MAT-file's numeric variables, and
+// optionally write its real double 2-D matrices back out with this writer.
+int mat_info(const std::string &src, const std::string &dst)
+{
+    std::vector<matio::Array> arrs;
+    std::string err;
+    if (!matio::read(src, {}, arrs, err)) {
+        fprintf(stderr, "%s\n", err.c_str());
+        return 1;
+    }
+    std::vector<matio::DoubleMatrix> vars;
+    for (auto &a : arrs) {
+        double sum = 0;
+        for (double v : a.f64) sum += v;
+        for (float v : a.f32) sum += v;
+        printf("%s %s", a.name.c_str(), a.is_single ? "single" : "double");
+        for (size_t dmn : a.dims) printf(" %zu", dmn);
+        printf(" sum=%.17g\n", sum);
+        if (!a.is_single && a.dims.size() == 2) vars.push_back({a.name, a.dims[0], a.dims[1], a.f64.data()});
+    }
+    if (!dst.empty() && !matio::write(dst, vars, err)) {
+        fprintf(stderr, "%s\n", err.c_str());
+        return 1;
+    }
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char *argv[])
+{
+    Options opt;
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        if (a.rfind("--mat-info=", 0) == 0) return mat_info(a.substr(11), "");
+        if (a.rfind("--mat-rewrite=", 0) == 0) {
+            const size_t c = a.find(':', 14);
+            if (c == std::string::npos) {
+                fprintf(stderr, "--mat-rewrite=SRC:DST\n");
+                return 1;
+            }
+            return mat_info(a.substr(14, c - 14), a.substr(c + 1));
+        }
+        if (a.rfind("--variant=", 0) == 0) opt.variant = a.substr(10);
+        else if (a.rfind("--seed=", 0) == 0) opt.seed = atol(a.c_str() + 7);
+        else if (a.rfind("--epochs=", 0) == 0) opt.epochs = atoi(a.c_str() + 9);
+        else if (a.rfind("--batch=", 0) == 0) opt.batch = atoi(a.c_str() + 8);
+        else if (a.rfind("--model=", 0) == 0) opt.model = a.substr(8);
+        else if (a == "--infer") opt.infer = true;
+        else opt.pos.push_back(a);
+    }
+    if (const char *e = getenv("CCNN_SEED"))
+        if (opt.seed < 0) opt.seed = atol(e);
+    const bool multi = opt.pos.size() == 3;
+    const Variant *v = multi ? &kMgpu
+                             : opt.variant == "sgd_fp64" ? &kSgd
+                             : opt.variant == "mbgd_fp64" ? &kMbgd64
+                             : opt.variant == "mbgd_fp32" ? &kMbgd32 : nullptr;
+    if (!v) {
+        fprintf(stderr, "unknown --variant '%s' (sgd_fp64, mbgd_fp64, mbgd_fp32)\n", opt.variant.c_str());
+        return 1;
+    }
+    const char *algo = v->sgd ? "SGD algo" : "MBGD algo";
+    fprintf(stdout, "[Cube CNN training with %s] ", algo);
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
+        fprintf(stderr, "There is no device.\n");   // InitCUDA, gcn_mbgd_fp64.cu:26-48
+        return 0;
+    }
+    printf("HIP initialized.\n");
+    fprintf(stdout, "[Cube CNN training with %s] Available Device List: ", algo);
+    for (int dv = 0; dv < count; dv++) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dv) != hipSuccess) continue;
+        printf(dv == 0 ? "Device %d -- %s(Default)  " : "Device %d -- %s  ", dv, prop.name);
+    }
+    printf("\n");
+    if (opt.pos.size() != 2 && opt.pos.size() != 3) {
+        // the single-GPU trainers ask for 3 arguments, the multi-GPU one for 4
+        // (gcn_mbgd_fp64.cu:1269-1272, hyper_version_mGPU_MBGD.cu:1355-1358)
+        fprintf(stderr, opt.pos.size() > 3 ? "4 input arguments required!\n" : "3 input arguments required!\n");
+        return 0;
+    }
+    if (opt.infer && opt.model.empty()) {
+        fprintf(stderr, "--infer needs --model=PATH\n");
+        return 1;
+    }
+    if (opt.batch <= 0 || opt.epochs < 0) {
+        fprintf(stderr, "--batch and --epochs must be positive\n");
+        return 1;
+    }
+    std::vector<int> devices;
+    if (multi) {
+        const int device_num = atoi(opt.pos[1].c_str()), master = atoi(opt.pos[2].c_str());
+        if (device_num <= 0 || device_num > count || master < 0 || master >= device_num) {
+            fprintf(stderr, "Device number error: %d device(s) available, asked for %d with master %d\n", count, device_num, master);
+            return 1;
+        }
+        devices.push_back(master);   // the master holds slice 0, the others follow in id order (:923-952)
+        for (int k = 0; k < device_num; k++)
+            if (k != master) devices.push_back(k);
+        fprintf(stdout, "[Cube CNN training with %s] Training implemented on %d Device(s), master %d.\n", algo, device_num, master);
+    } else {
+        const int dv = atoi(opt.pos[1].c_str());
+        if (dv < 0 || dv >= count) {
+            fprintf(stderr, "%s:%d: invalid device ordinal %d\n", __FILE__, __LINE__, dv);
+            return 1;
+        }
+        devices.push_back(dv);
+        fprintf(stdout, "[Cube CNN training with %s] Training implemented on Device %d.\n", algo, dv);
+    }
+
+    std::vector<matio::Array> arrs;
+    std::string err;
+    if (!matio::read(opt.pos[0], {"DataSet", "labels"}, arrs, err)) {
+        fprintf(stderr, "%s\n", err.c_str());
+        return 1;
+    }
+    const matio::Array *scene = nullptr, *lab = nullptr;
+    for (auto &a : arrs) {
+        if (a.name == "DataSet") scene = &a;
+        if (a.name == "labels") lab = &a;
+    }
+    if (!scene || !lab || scene->dims.size() != 3 || lab->numel() != scene->dims[0] * scene->dims[1]) {
+        fprintf(stderr, "'%s' must hold DataSet (x-by-y-by-z) and labels (x-by-y)\n", opt.pos[0].c_str());
+        return 1;
+    }
+    const int x = (int)scene->dims[0], y = (int)scene->dims[1], z = (int)scene->dims[2];
+    std::vector<double> labels(lab->numel());
+    for (size_t i = 0; i < labels.size(); i++) labels[i] = lab->is_single ? (double)lab->f32[i] : lab->f64[i];
+
+    const double correct = v->f32 ? run<float>(opt, *v, *scene, labels, x, y, z, devices)
+                                  : run<double>(opt, *v, *scene, labels, x, y, z, devices);
+    fprintf(stdout, "Accuracy: %.3f%% \n", correct * 100);
+    return 0;
+}

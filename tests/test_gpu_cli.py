@@ -1,0 +1,134 @@
+"""GPU: the `gcn` command line end to end on a small synthetic .mat dataset --
+stdout lines in the reference's format (tools/run.sh field positions), model.mat
+contents and accuracy against the oracle's replay of the same run."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import scipy.io as sio
+
+import oracle as orc
+import synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GCN = os.path.join(ROOT, "gcn_amd", "bin", "gcn")
+X, Y, Z, SEED = 24, 20, 60, 77
+
+
+def make_dataset(tmp_path, dtype):
+    scene, labels = synth.small_scene(X, Y, Z, 3)
+    ds = scene.reshape(Z, Y, X).transpose(2, 1, 0).astype(dtype)      # MATLAB x-by-y-by-z, column-major on disk
+    lab = labels.reshape(Y, X).T
+    path = str(tmp_path / "DATASET.mat")
+    sio.savemat(path, {"DataSet": ds, "labels": lab}, do_compression=True)
+    return path, scene, labels
+
+
+def run_gcn(tmp_path, args):
+    assert os.path.exists(GCN), "build the CLI with __graft_entry__.build()"
+    r = subprocess.run([GCN] + args, cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    return r.stdout
+
+
+def oracle_run(scene, labels, dtype, B, lr, epochs, sgd=False, fifo=1.0):
+    d = orc.dims(Z)
+    di = orc.scan_labels(labels, X, Y)
+    tr9, te9, onehot, tl = orc.build_index(labels, di, X, Y)
+    orc.shuffle(tr9, onehot, SEED)
+    p = orc.init_params_f32(Z) if dtype == np.float32 else orc.init_params_f64(Z, d.pout if sgd else d.pout * B)
+    sc = scene.astype(dtype)
+    train, test = orc.gather(sc, tr9, X, Y, Z), orc.gather(sc, te9, X, Y, Z)
+    T = len(onehot)
+    losses = []
+    cur = dtype(lr)
+    sched = orc.Sched(dtype, fifo)
+    for _ in range(epochs):
+        if sgd:
+            rate = orc.sgd_f64(p, train, onehot, 0, T, Z, float(cur)) / T
+        else:
+            tot = dtype(0) if dtype == np.float32 else 0.0
+            for i0 in range(T // B):
+                lv, _, _ = orc.mbgd_step(p, train, onehot, i0 * B, B, Z, cur, want_grad=False)
+                for v in lv:
+                    tot = dtype(np.float64(tot) + v) if dtype == np.float32 else tot + v
+            rate = float(tot) / T
+        losses.append(rate)
+        _, nl = sched.step(rate, float(cur))
+        cur = dtype(nl)
+    _, am = orc.forward(p, test, Z)
+    return p, losses, float(np.mean(am + 1 == tl)), d
+
+
+def parse(stdout):
+    losses = [float(m) for m in re.findall(r"Iteration \d+,\s+loss = ([0-9.eE+-]+);", stdout)]
+    acc_line = [l for l in stdout.splitlines() if "Accuracy" in l][0]
+    glob_line = [l for l in stdout.splitlines() if "Global" in l][0]
+    return losses, acc_line, glob_line
+
+
+@pytest.mark.parametrize("variant,dtype,lr,fifo", [("mbgd_fp32", np.float32, 0.04, 100.0), ("mbgd_fp64", np.float64, 0.5, 1.0)])
+def test_mbgd_cli_matches_oracle(tmp_path, variant, dtype, lr, fifo):
+    path, scene, labels = make_dataset(tmp_path, dtype)
+    B, epochs = 20, 3
+    out = run_gcn(tmp_path, [f"--variant={variant}", f"--seed={SEED}", f"--epochs={epochs}", f"--batch={B}", path, "0"])
+    p_ref, l_ref, acc_ref, d = oracle_run(scene, labels, dtype, B, lr, epochs, fifo=fifo)
+    losses, acc_line, glob_line = parse(out)
+    assert len(losses) == epochs
+    assert np.allclose(losses, l_ref, rtol=2e-5, atol=1e-6)          # printed with %lf (6 decimals)
+    # tools/run.sh: accuracy = field 10, test time = field 7 of the Accuracy line; train time = field 16 (MBGD)
+    f = acc_line.split(" ")
+    assert f[8] == "Accuracy:" and f[9].endswith("%") and float(f[6]) >= 0
+    assert abs(float(f[9].rstrip("%")) - 100 * acc_ref) <= 0.1 + 1e-9
+    g = glob_line.split(" ")
+    assert g[11] == "Global" and g[12] == "Exesution" and float(g[15]) > 0
+    assert f"BatchSize = {B}]" in glob_line
+    m = sio.loadmat(str(tmp_path / "model" / "model.mat"))
+    assert m["filters"].shape == (171, 20) and m["omega1"].shape == (100, d.pout) and m["loss"].shape == (300, 1)
+    got = np.concatenate([m[k].ravel(order="F") for k in ("filters", "bias0", "omega1", "bias1", "omega2", "bias2")])
+    tol = 1e-5 if dtype == np.float32 else 1e-11
+    assert np.abs(got - p_ref).max() <= tol * np.abs(p_ref).max()
+    assert np.allclose(m["loss"].ravel()[:epochs], l_ref, rtol=10 * tol)
+
+
+def test_sgd_cli_and_inference_mode(tmp_path):
+    path, scene, labels = make_dataset(tmp_path, np.float64)
+    epochs = 2
+    out = run_gcn(tmp_path, ["--variant=sgd_fp64", f"--seed={SEED}", f"--epochs={epochs}", path, "0"])
+    p_ref, l_ref, acc_ref, d = oracle_run(scene, labels, np.float64, 1, 0.008, epochs, sgd=True)
+    losses, acc_line, glob_line = parse(out)
+    assert np.allclose(losses, l_ref, rtol=2e-5, atol=1e-6)
+    g = glob_line.split(" ")
+    assert g[7] == "Global" and float(g[11]) > 0                      # run.sh field 12 for SGD
+    acc = float(acc_line.split(" ")[9].rstrip("%"))
+    assert abs(acc - 100 * acc_ref) <= 0.1 + 1e-9
+    m = sio.loadmat(str(tmp_path / "model.mat"))                      # SGD writes ./model.mat with its own names
+    got = np.concatenate([m[k].ravel(order="F") for k in ("filters", "conv_bias", "fulconnect_weights",
+                                                          "fulconnect_bias", "output_weights", "output_bias")])
+    assert np.abs(got - p_ref).max() <= 1e-10 * np.abs(p_ref).max()
+    # load the saved model back and only run the test loop
+    out2 = run_gcn(tmp_path, ["--variant=sgd_fp64", f"--seed={SEED}", "--infer", "--model=model.mat", path, "0"])
+    assert "Iteration" not in out2
+    assert abs(float([l for l in out2.splitlines() if "Accuracy" in l][0].split(" ")[9].rstrip("%")) - acc) < 1e-9
+
+
+def test_multi_gpu_form_with_one_device(tmp_path):
+    """`gcn DATASET.mat device_num master_dev_id` with device_num = 1 is the fp64 minibatch trainer."""
+    path, scene, labels = make_dataset(tmp_path, np.float64)
+    B, epochs = 20, 2
+    out = run_gcn(tmp_path, [f"--seed={SEED}", f"--epochs={epochs}", f"--batch={B}", path, "1", "0"])
+    _, l_ref, acc_ref, _ = oracle_run(scene, labels, np.float64, B, 0.5, epochs)
+    losses, acc_line, _ = parse(out)
+    assert np.allclose(losses, l_ref, rtol=2e-5, atol=1e-6)
+    assert abs(float(acc_line.split(" ")[9].rstrip("%")) - 100 * acc_ref) <= 0.1 + 1e-9
+
+
+def test_argument_errors(tmp_path):
+    r = subprocess.run([GCN, "only_one_arg"], cwd=tmp_path, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "3 input arguments required!" in r.stderr      # gcn_mbgd_fp64.cu:1269-1272
+    r = subprocess.run([GCN, "missing.mat", "0"], cwd=tmp_path, capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "cannot open" in r.stderr

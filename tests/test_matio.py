@@ -1,0 +1,67 @@
+"""CPU: the CLI's own MAT-file (Level 5) reader/writer against scipy.io, through the
+`gcn --mat-info / --mat-rewrite` utilities (they run before any device is touched)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import scipy.io as sio
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GCN = os.path.join(ROOT, "gcn_amd", "bin", "gcn")
+
+pytestmark = pytest.mark.skipif(not os.path.exists(GCN), reason="gcn CLI not built")
+
+
+def info(path):
+    r = subprocess.run([GCN, f"--mat-info={path}"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    out = {}
+    for line in r.stdout.splitlines():
+        parts = line.split()
+        out[parts[0]] = (parts[1], tuple(int(v) for v in parts[2:-1]), float(parts[-1].split("=")[1]))
+    return out
+
+
+@pytest.mark.parametrize("compress", [False, True])
+def test_reader_handles_classes_compression_and_3d(tmp_path, compress):
+    rng = np.random.default_rng(0)
+    ds64 = rng.random((7, 6, 5))
+    ds32 = ds64.astype(np.float32)
+    lab = (np.arange(42).reshape(7, 6) % 14).astype(np.float64)
+    p = str(tmp_path / "a.mat")
+    sio.savemat(p, {"DataSet": ds64, "single3d": ds32, "labels": lab, "lab_u8": lab.astype(np.uint8),
+                    "lab_i16": lab.astype(np.int16), "abc": np.array([[1.5]]), "name_longer_than_8": lab[:2]},
+                do_compression=compress)
+    got = info(p)
+    assert got["DataSet"][:2] == ("double", (7, 6, 5)) and abs(got["DataSet"][2] - ds64.sum()) < 1e-9
+    assert got["single3d"][:2] == ("single", (7, 6, 5)) and abs(got["single3d"][2] - ds32.astype(np.float64).sum()) < 1e-3
+    for k in ("labels", "lab_u8", "lab_i16"):
+        assert got[k][1] == (7, 6) and got[k][2] == lab.sum(), k           # integer classes come back as doubles
+    assert got["abc"][2] == 1.5 and got["name_longer_than_8"][1] == (2, 6)
+
+
+def test_writer_round_trips_through_scipy(tmp_path):
+    rng = np.random.default_rng(1)
+    mats = {"filters": rng.normal(size=(171, 20)), "bias0": rng.normal(size=(20, 1)), "b": rng.normal(size=(3, 1)),
+            "loss": rng.random((300, 1)), "omega1_long_name": rng.normal(size=(100, 40))}
+    src, dst = str(tmp_path / "s.mat"), str(tmp_path / "d.mat")
+    sio.savemat(src, mats)
+    r = subprocess.run([GCN, f"--mat-rewrite={src}:{dst}"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    back = sio.loadmat(dst)
+    for k, v in mats.items():
+        assert np.array_equal(back[k], v), k
+
+
+def test_reader_rejects_what_it_cannot_read(tmp_path):
+    p = tmp_path / "v73.mat"
+    p.write_bytes(b"MATLAB 7.3 MAT-file, Platform: GLNXA64" + b" " * 200)
+    r = subprocess.run([GCN, f"--mat-info={p}"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "v7.3" in r.stderr
+    q = tmp_path / "junk.mat"
+    q.write_bytes(b"not a mat file")
+    r = subprocess.run([GCN, f"--mat-info={q}"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0
+    r = subprocess.run([GCN, f"--mat-info={tmp_path / 'absent.mat'}"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "cannot open" in r.stderr
