@@ -182,16 +182,16 @@ struct Device {
 };
 
 template <typename T>
-int gather_on(const T *scene, const int *idx, long n, int x, int y, int z, T *out, hipStream_t st);
+int gather_on(const T *scene, const int *idx, long n, int x, int y, int z, T *out, void *ws, size_t wsb);
 template <>
-int gather_on<float>(const float *s, const int *i, long n, int x, int y, int z, float *o, hipStream_t st)
+int gather_on<float>(const float *s, const int *i, long n, int x, int y, int z, float *o, void *ws, size_t wsb)
 {
-    return ccnn_gather_f32(s, i, n, x, y, z, o, st);
+    return ccnn_gather_f32(s, i, n, x, y, z, o, ws, wsb, nullptr);
 }
 template <>
-int gather_on<double>(const double *s, const int *i, long n, int x, int y, int z, double *o, hipStream_t st)
+int gather_on<double>(const double *s, const int *i, long n, int x, int y, int z, double *o, void *ws, size_t wsb)
 {
-    return ccnn_gather_f64(s, i, n, x, y, z, o, st);
+    return ccnn_gather_f64(s, i, n, x, y, z, o, ws, wsb, nullptr);
 }
 
 template <typename T>
@@ -229,9 +229,14 @@ double run(const Options &opt, const Variant &v, const matio::Array &scene_a, co
     T *scene_d = to_device(scene);
     int *tr_idx_d = to_device(s.train_idx9), *te_idx_d = to_device(s.test_idx9);
     T *train_d = dmalloc<T>((size_t)s.n_train * d.cube), *test_d = dmalloc<T>((size_t)s.n_test * d.cube);
-    CK(gather_on<T>(scene_d, tr_idx_d, s.n_train, x, y, z, train_d, nullptr));
-    CK(gather_on<T>(scene_d, te_idx_d, s.n_test, x, y, z, test_d, nullptr));
+    const size_t gws_bytes = ccnn_gather_workspace_bytes(s.n_train);   // sized for the larger list
+    void *gws = nullptr;
+    if (gws_bytes) CK(hipMalloc(&gws, gws_bytes));
+    CK(gather_on<T>(scene_d, tr_idx_d, s.n_train, x, y, z, train_d, gws, gws_bytes));
+    // the test list is already in pixel order: no ordering pass needed
+    CK(gather_on<T>(scene_d, te_idx_d, s.n_test, x, y, z, test_d, nullptr, 0));
     CK(hipDeviceSynchronize());
+    if (gws) CK(hipFree(gws));
     fprintf(stdout,
             "[Samples prepared with %d Nearest-Neighbor-Pixels Strategy] Proportion of Training Samples: %d%%  Execution "
             "time: %.3f sec\n",

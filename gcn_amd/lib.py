@@ -30,8 +30,9 @@ _SIG = {
     # name: (restype, argtypes)
     "ccnn_get_dims": (C.c_int, [C.c_int, C.POINTER(Dims)]),
     "ccnn_error_string": (C.c_char_p, [C.c_int]),
-    "ccnn_gather_f32": (C.c_int, [_P, _P, C.c_long, C.c_int, C.c_int, C.c_int, _P, _P]),
-    "ccnn_gather_f64": (C.c_int, [_P, _P, C.c_long, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "ccnn_gather_workspace_bytes": (C.c_size_t, [C.c_long]),
+    "ccnn_gather_f32": (C.c_int, [_P, _P, C.c_long, C.c_int, C.c_int, C.c_int, _P, _P, C.c_size_t, _P]),
+    "ccnn_gather_f64": (C.c_int, [_P, _P, C.c_long, C.c_int, C.c_int, C.c_int, _P, _P, C.c_size_t, _P]),
     "ccnn_forward_workspace_bytes": (C.c_size_t, [C.c_long, C.c_int, C.c_int]),
     "ccnn_forward_f32": (C.c_int, [_P, _P, C.c_long, C.c_int, _P, _P, _P, C.c_size_t, _P]),
     "ccnn_forward_f64": (C.c_int, [_P, _P, C.c_long, C.c_int, _P, _P, _P, C.c_size_t, _P]),

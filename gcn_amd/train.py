@@ -186,7 +186,7 @@ def prepare(scene, labels, x, y, z, dtype, seed, pool_bias_draws=None, device="c
     scene_d = torch.from_numpy(np.ascontiguousarray(scene, dtype=npdt)).to(device)
     out = dict(
         train_cubes=ops.gather(scene_d, torch.from_numpy(tr9).to(device), x, y, z),
-        test_cubes=ops.gather(scene_d, torch.from_numpy(te9).to(device), x, y, z),
+        test_cubes=ops.gather(scene_d, torch.from_numpy(te9).to(device), x, y, z, sort=False),   # already in pixel order
         onehot=torch.from_numpy(onehot).to(device),
         test_labels=torch.from_numpy(test_labels).to(device),
         params=torch.from_numpy(params).to(device),

@@ -72,11 +72,15 @@ const char *ccnn_error_string(int code);
  * 846-847; gcn_sgd_fp64.cu:470-486, 709-710) and processing<<<64,1024>>>
  * (preprocess048.cu:50-65, 229-232).  out[i*9z + b*9 + j] =
  * scene[idx9[i*9+j] + b*x*y] for every i < n (the trainers' single iter=0 launch
- * stops at 32768 / 65536 samples; this gathers all n like preprocess048 does). */
+ * stops at 32768 / 65536 samples; this gathers all n like preprocess048 does).
+ * workspace is optional (NULL, 0): with ccnn_gather_workspace_bytes(n) bytes the
+ * samples are visited in centre-pixel order, which lets neighbouring pixels share
+ * their reads; the result is the same either way. */
+size_t ccnn_gather_workspace_bytes(long n);
 int ccnn_gather_f32(const float *scene, const int *idx9, long n, int x, int y, int z,
-                    float *out, void *stream);
+                    float *out, void *workspace, size_t workspace_bytes, void *stream);
 int ccnn_gather_f64(const double *scene, const int *idx9, long n, int x, int y, int z,
-                    double *out, void *stream);
+                    double *out, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Forward pass over n cubes: the test loop's convolution / maxpooling /
  * fully_connect / output_and_dvalue(false) launches plus the host count_err
