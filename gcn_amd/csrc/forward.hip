@@ -3,9 +3,10 @@
 //
 // Kernel map (reference kernel -> here)
 //   convolution + maxpooling   -> conv_pool_fwd  (implicit GEMM on MFMA: positions x taps x filters)
-//   fully_connect              -> fc1_partial (MFMA, K split in 64-wide chunks) + head
-//   output_and_dvalue(false)   -> head
-//   count_err                  -> head (device argmax) + count_correct_kernel
+//   fully_connect,
+//   output_and_dvalue(false),
+//   count_err                  -> fc_head_fwd (FC1 on MFMA with W1 streamed through LDS, then the
+//                                 output layer, softmax and device argmax) + count_correct_kernel
 //   update_params_row/col      -> update_*_kernel (after an all-reduce; single-GPU training
 //                                 fuses the update into grad_reduce, see mbgd.hip)
 #include <map>
@@ -74,178 +75,172 @@ size_t conv_smem(const ccnn_dims_t &d)
 }
 
 // ---------------------------------------------------------------------------
-// FC1 partial products: z1part[c][row][n] = sum_{p in chunk c} pool[row][p] * W1[n + 100 p].
-// grid (chunks, ceil(nrows/16)); a [16 x 64] x [64 x 100] product per workgroup,
-// the 7 neuron tiles spread over the 4 waves.
+// FC1 + tanh + output layer + softmax + count_err argmax for 32 samples per
+// workgroup (fully_connect, output_and_dvalue(false), count_err:
+// gcn_mbgd_fp64.cu:271-354, 628-652).
+//
+// FC1 is a [32 x Pout] x [Pout x 100] MFMA product: the K loop walks W1 in chunks of
+// 64 pooled features (25.6 KB, contiguous in W1) staged through LDS; the next chunk's
+// global loads are issued before the current chunk's MFMAs and stored after them.
+// Wave w owns sample tile w&1 and neuron tiles {0..3} (w<2) or {4..6}.
+// The epilogue runs from LDS: 8 lanes per sample, lane j producing outputs j and j+8.
+constexpr int FH_MS = 32;                      // samples per workgroup
+constexpr int LDZ = H + 1;                     // z1/a1 rows in LDS (odd stride)
+
 template <typename T>
-__global__ __launch_bounds__(256) void fc1_partial(const T *__restrict__ W1,
-                                                   const T *__restrict__ pool, int nrows, int pout,
-                                                   T *__restrict__ z1part)
+struct FcHeadLds {
+    static constexpr int wl = 0;                                   // [64][LDW1]   W1 chunk; later z1s[32][LDZ]
+    static constexpr int pt = wl + PCHUNK * LDW1;                  // [32][LDP]    pool chunk
+    static constexpr int w2 = pt + ((FH_MS * LDP + 3) & ~3);       // [1300]       W2
+    static constexpr int b1 = w2 + ((H * O + 3) & ~3);             // [100]
+    static constexpr int b2 = b1 + H;                              // [16]
+    static constexpr int es = b2 + 16;                             // [32][16]
+    static constexpr int ps = es + FH_MS * 16;                     // [32][16]
+    static constexpr int total = ps + FH_MS * 16;
+    static constexpr size_t bytes = (size_t)total * sizeof(T);
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params, int off_w1, int off_b1,
+                                                   int off_w2, int off_b2, const T *__restrict__ pool,
+                                                   int nrows, int pout, T *__restrict__ probs,
+                                                   int *__restrict__ argmax)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T *wl = reinterpret_cast<T *>(smem);   // [64][LDW1]
-    T *pt = wl + PCHUNK * LDW1;            // [16][LDP]
+    typedef FcHeadLds<T> L;
+    typedef typename Vec16<T>::type V;
+    constexpr int VW = Vec16<T>::W;
+    T *base = reinterpret_cast<T *>(smem);
+    T *wl = base + L::wl, *pt = base + L::pt, *w2s = base + L::w2, *b1s = base + L::b1, *b2s = base + L::b2;
+    T *es = base + L::es, *ps = base + L::ps;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15, kq = lane >> 4;
-    const int c = blockIdx.x;
-    const int r0 = blockIdx.y * 16;
-    const int p0 = c * PCHUNK;
-    const int pmax = min(PCHUNK, pout - p0);
-    // zero what the loads below do not cover: neuron columns 100..111, rows past the
-    // chunk's end, and the whole pool tile (ragged batch / last chunk)
-    for (int e = tid; e < PCHUNK * LDW1; e += 256) {
-        const int p = e / LDW1, n = e - p * LDW1;
-        if (n >= H || p >= pmax) wl[e] = 0;
-    }
-    for (int e = tid; e < 16 * LDP; e += 256) pt[e] = 0;
-    __syncthreads();
-    // the chunk is contiguous in W1 ([p][100]) and 16-byte aligned (100 p0 and off_w1 are multiples of 4)
-    constexpr int VW = Vec16<T>::W;
-    stage_vec<7, 256>(W1 + (long)p0 * H, pmax * H / VW, tid, [&](int e, typename Vec16<T>::type v) {
-        const int p = (e * VW) / H, n = e * VW - p * H;
-        *reinterpret_cast<typename Vec16<T>::type *>(wl + p * LDW1 + n) = v;
-    });
-    {
-        const int nb = min(16, nrows - r0);
-        T tmp[4];
+    const int r0 = blockIdx.x * FH_MS;
+    const int nb = min(FH_MS, nrows - r0);
+    const T *W1 = params + off_w1;
+    const int nch = (pout + PCHUNK - 1) / PCHUNK;
+
+    stage<6, 256>(params + off_w2, H * O, tid, [&](int e, T v) { w2s[e] = v; });
+    if (tid < H) b1s[tid] = params[off_b1 + tid];
+    if (tid < O) b2s[tid] = params[off_b2 + tid];
+    // neuron columns 100..111 of the W1 image are never loaded: keep them zero
+    for (int e = tid; e < PCHUNK * (LDW1 - H); e += 256) wl[(e / (LDW1 - H)) * LDW1 + H + e % (LDW1 - H)] = 0;
+
+    const int mtile = wave & 1;
+    const int nt0 = (wave >> 1) ? 4 : 0;
+    const T *ap = pt + (mtile * 16 + col) * LDP + kq;
+    const T *bp = wl + kq * LDW1 + nt0 * 16 + col;
+    typename Mma<T>::acc_t acc[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+    for (int j = 0; j < 4; j++) acc[j] = typename Mma<T>::acc_t{0, 0, 0, 0};
+
+    constexpr int NWV = (PCHUNK * H / VW + 255) / 256;      // W1 vectors per thread per chunk
+    constexpr int NPT = FH_MS * PCHUNK / 256;               // pool elements per thread per chunk
+    V wreg[NWV];
+    T preg[NPT];
+    auto issue = [&](int c) {   // global loads of chunk c into registers (clamped, unconditional)
+        const int p0 = c * PCHUNK;
+        const int pmax = min(PCHUNK, pout - p0);
+        const int nvec = pmax * H / VW;
+        const V *src = reinterpret_cast<const V *>(W1 + (long)p0 * H);
+#pragma unroll
+        for (int u = 0; u < NWV; u++) wreg[u] = src[min(u * 256 + tid, nvec - 1)];
+#pragma unroll
+        for (int u = 0; u < NPT; u++) {
             const int e = u * 256 + tid, b = e >> 6, p = e & 63;
-            const T x = pool[(long)(r0 + min(b, nb - 1)) * pout + p0 + min(p, pmax - 1)];   // clamped load
-            tmp[u] = (b < nb && p < pmax) ? x : T(0);
+            preg[u] = pool[(long)(r0 + min(b, nb - 1)) * pout + p0 + min(p, pmax - 1)];
         }
+    };
+    auto commit = [&](int c) {   // registers -> LDS images of chunk c
+        const int p0 = c * PCHUNK;
+        const int pmax = min(PCHUNK, pout - p0);
+        const int nvec = pmax * H / VW;
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < NWV; u++) {
+            const int e = u * 256 + tid;
+            if (e < nvec) {
+                const int p = (e * VW) / H, n = e * VW - p * H;
+                *reinterpret_cast<V *>(wl + p * LDW1 + n) = wreg[u];
+            }
+        }
+        if (pmax < PCHUNK)   // last chunk: rows past the end must read as zero
+            for (int e = pmax * LDW1 + tid; e < PCHUNK * LDW1; e += 256) wl[e] = 0;
+#pragma unroll
+        for (int u = 0; u < NPT; u++) {
             const int e = u * 256 + tid, b = e >> 6, p = e & 63;
-            pt[b * LDP + p] = tmp[u];
+            pt[b * LDP + p] = (b < nb && p < pmax) ? preg[u] : T(0);
+        }
+    };
+
+    issue(0);
+    __syncthreads();
+    commit(0);
+    for (int c = 0; c < nch; c++) {
+        __syncthreads();                     // chunk c is in LDS
+        if (c + 1 < nch) issue(c + 1);       // next chunk's loads fly during the MFMAs
+        for (int s = 0; s < PCHUNK / 4; s += 4) {
+            T a[4], b[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                a[u] = ap[4 * (s + u)];
+#pragma unroll
+                for (int j = 0; j < 4; j++) b[u][j] = bp[4 * (s + u) * LDW1 + 16 * (wave >> 1 && j == 3 ? 2 : j)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[j] = Mma<T>::mma(a[u], b[u][j], acc[j]);
+        }
+        __syncthreads();                     // everyone is done reading chunk c
+        if (c + 1 < nch) commit(c + 1);
+    }
+
+    // ---- epilogue: z1 -> LDS, then 8 lanes per sample --------------------------------
+    T *z1s = wl;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int n = (nt0 + j) * 16 + col;
+        if (n < H && !(wave >> 1 && j == 3)) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) z1s[(mtile * 16 + Mma<T>::row(lane, r)) * LDZ + n] = acc[j][r];
         }
     }
     __syncthreads();
-    const int n0 = wave * 16, n1 = (wave + 4) * 16;
-    const bool two = n1 < H;   // waves 0..2 own two neuron tiles, wave 3 one
-    const T *ap = pt + col * LDP + kq;
-    const T *bp0 = wl + kq * LDW1 + n0 + col;
-    const T *bp1 = wl + kq * LDW1 + (two ? n1 : n0) + col;
-    typename Mma<T>::acc_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-    for (int s = 0; s < PCHUNK / 4; s += 4) {
-        T a[4], b0[4], b1[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            a[u] = ap[4 * (s + u)];
-            b0[u] = bp0[4 * (s + u) * LDW1];
-            b1[u] = bp1[4 * (s + u) * LDW1];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            acc0 = Mma<T>::mma(a[u], b0[u], acc0);
-            acc1 = Mma<T>::mma(a[u], b1[u], acc1);   // wave 3 repeats its first tile; discarded below
-        }
+    const int s = tid >> 3, j8 = tid & 7;
+    T *zr = z1s + s * LDZ;
+    for (int n = j8; n < H; n += 8) zr[n] = 2 / (1 + 1 / rexp((zr[n] + b1s[n]) * 2)) - 1;   // gcn_mbgd_fp64.cu:302
+    __syncthreads();
+    const int o0 = j8, o1 = j8 + 8;          // lane j8 produces outputs j8 and j8+8 (the latter for j8 < 5)
+    const bool has1 = o1 < O;
+    T m0 = 0, m1 = 0;
+    for (int i = 0; i < H; i++) {
+        const T a = zr[i];
+        m0 = m0 + w2s[o0 + i * O] * a;
+        m1 = m1 + w2s[(has1 ? o1 : o0) + i * O] * a;
     }
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int b = r0 + Mma<T>::row(lane, r);
-        if (b < nrows) {
-            T *dst = z1part + ((long)c * nrows + b) * H;
-            if (n0 + col < H) dst[n0 + col] = acc0[r];
-            if (two && n1 + col < H) dst[n1 + col] = acc1[r];
-        }
+    const T e0 = rexp(m0 + b2s[o0]), e1 = rexp(m1 + b2s[has1 ? o1 : o0]);
+    es[s * 16 + o0] = e0;
+    if (has1) es[s * 16 + o1] = e1;
+    __syncthreads();
+    const T sum = tree13(es + s * 16);
+    const T p0 = e0 / sum, p1 = e1 / sum;
+    ps[s * 16 + o0] = p0;
+    if (has1) ps[s * 16 + o1] = p1;
+    if (s < nb && probs) {
+        probs[(long)(r0 + s) * O + o0] = p0;
+        if (has1) probs[(long)(r0 + s) * O + o1] = p1;
     }
-}
-
-template <typename T>
-constexpr size_t fc1_smem()
-{
-    return (size_t)(PCHUNK * LDW1 + 16 * LDP) * sizeof(T);
-}
-
-// ---------------------------------------------------------------------------
-// FC1 epilogue + output layer + softmax (+ loss, delta2, delta1 when onehot given)
-// + count_err argmax.  128 threads, grid-stride over samples; W2/b2/b1 are staged
-// in LDS once per workgroup.
-template <typename T>
-__global__ __launch_bounds__(128) void head(const T *__restrict__ params, int off_b1, int off_w2,
-                                            int off_b2, const T *__restrict__ z1part, int nch,
-                                            int nrows, const int *__restrict__ onehot,
-                                            T *__restrict__ a1out, T *__restrict__ d1out,
-                                            T *__restrict__ d2out, T *__restrict__ probs,
-                                            int *__restrict__ argmax,
-                                            double *__restrict__ loss_values)
-{
-    __shared__ T w2s[H * O];
-    __shared__ T a1s[H];
-    __shared__ T es[16];
-    __shared__ T ps[16];
-    __shared__ T d2s[16];
-    const int n = threadIdx.x;
-    stage<11, 128>(params + off_w2, H * O, n, [&](int e, T v) { w2s[e] = v; });
-    const T b1 = n < H ? params[off_b1 + n] : T(0);
-    // output unit o = n >> 3 (13 x 8 threads), each summing every 8th hidden unit
-    const int o8 = n >> 3, j8 = n & 7;
-    const T b2 = o8 < O ? params[off_b2 + o8] : T(0);
-
-    for (long b = blockIdx.x; b < nrows; b += gridDim.x) {
-        __syncthreads();   // previous sample's a1s/es/ps/d2s readers are done (and w2s is staged)
-        T a = 0;
-        if (n < H) {
-            T zsum = 0;
-            const T *zp = z1part + b * H + n;
-            const long cs = (long)nrows * H;
-            int c = 0;
-            for (; c + 4 <= nch; c += 4) {
-                const T z0 = zp[c * cs], z1 = zp[(c + 1) * cs], z2 = zp[(c + 2) * cs], z3 = zp[(c + 3) * cs];
-                zsum = (((zsum + z0) + z1) + z2) + z3;
+    __syncthreads();
+    if (argmax && j8 == 0 && s < nb) {
+        // count_err: running max starts at 0, strict '>' (gcn_mbgd_fp64.cu:636-647)
+        T mx = 0;
+        int idx = 0;
+        for (int i = 0; i < O; i++)
+            if (ps[s * 16 + i] > mx) {
+                mx = ps[s * 16 + i];
+                idx = i;
             }
-            for (; c < nch; c++) zsum = zsum + zp[c * cs];
-            a = 2 / (1 + 1 / rexp((zsum + b1) * 2)) - 1;   // gcn_mbgd_fp64.cu:302
-            a1s[n] = a;
-            if (a1out) a1out[b * H + n] = a;
-        }
-        __syncthreads();
-        {
-            T mid = 0;
-            if (o8 < O)
-                for (int i = j8; i < H; i += 8) mid = mid + w2s[o8 + i * O] * a1s[i];
-            mid += __shfl_xor(mid, 4);
-            mid += __shfl_xor(mid, 2);
-            mid += __shfl_xor(mid, 1);
-            if (o8 < O && j8 == 0) es[o8] = rexp(mid + b2);
-        }
-        __syncthreads();
-        if (n < O) {
-            const T p = es[n] / tree13(es);
-            ps[n] = p;
-            if (probs) probs[b * O + n] = p;
-            if (onehot) {
-                const T d = (p - onehot[b * O + n]) / O;   // gcn_mbgd_fp64.cu:352
-                d2s[n] = d;
-                d2out[b * O + n] = d;
-            }
-        }
-        __syncthreads();
-        if (n == 127) {
-            if (argmax) {   // count_err: running max starts at 0, strict '>' (gcn_mbgd_fp64.cu:636-647)
-                T mx = 0;
-                int idx = 0;
-                for (int i = 0; i < O; i++)
-                    if (ps[i] > mx) {
-                        mx = ps[i];
-                        idx = i;
-                    }
-                argmax[b] = idx;
-            }
-            if (onehot && loss_values) {
-                T ta[O], tb[O];
-                for (int i = 0; i < O; i++) loss_terms(ps[i], onehot[b * O + i], &ta[i], &tb[i]);
-                loss_values[b] = loss_sum(ta, tb, onehot + b * O);
-            }
-        }
-        if (onehot && n < H) {
-            // bp_fully_connect(out -> hidden), gcn_mbgd_fp64.cu:416-434: 13-wide tree
-            T prod[O];
-#pragma unroll
-            for (int o = 0; o < O; o++) prod[o] = w2s[o + n * O] * d2s[o];
-            d1out[b * H + n] = tree13(prod) * (1 + a) * (1 - a);
-        }
+        argmax[r0 + s] = idx;
     }
 }
 
@@ -292,22 +287,17 @@ __global__ void count_correct_kernel(const int *__restrict__ argmax, const int *
 // ---------------------------------------------------------------------------
 // host-side orchestration
 
-constexpr long FWD_CHUNK = 8192;   // samples per forward pass through the workspace
+constexpr long FWD_CHUNK = 16384;  // samples per forward pass through the workspace
 constexpr int PERSIST_GRID = 1024; // workgroups for the grid-stride kernels
 
 template <typename T>
 struct FwdWs {
-    T *pool, *z1part;
-    static size_t bytes(long rows, const ccnn_dims_t &d)
-    {
-        return align_up((size_t)rows * d.pout * sizeof(T)) +
-               align_up((size_t)nchunks(d.pout) * rows * H * sizeof(T));
-    }
+    T *pool;
+    static size_t bytes(long rows, const ccnn_dims_t &d) { return align_up((size_t)rows * d.pout * sizeof(T)); }
     FwdWs(void *ws, long rows, const ccnn_dims_t &d)
     {
         Carver c(ws);
         pool = c.take<T>((size_t)rows * d.pout);
-        z1part = c.take<T>((size_t)nchunks(d.pout) * rows * H);
     }
 };
 
@@ -322,9 +312,8 @@ int forward_impl(const T *params, const T *cubes, long n, int z, T *probs, int *
     const long rows = n < FWD_CHUNK ? n : FWD_CHUNK;
     if (ws_bytes < FwdWs<T>::bytes(rows, d)) return CCNN_E_WORKSPACE;
     FwdWs<T> w(ws, rows, d);
-    const int nch = nchunks(d.pout);
     if (int e = allow_smem(conv_pool_fwd<T, FLIP>, conv_smem<T>(d))) return e;
-    if (int e = allow_smem(fc1_partial<T>, fc1_smem<T>())) return e;
+    if (int e = allow_smem(fc_head_fwd<T>, FcHeadLds<T>::bytes)) return e;
     for (long s0 = 0; s0 < n; s0 += rows) {
         const int nr = (int)((n - s0) < rows ? (n - s0) : rows);
         const int pg = nr < PERSIST_GRID ? nr : PERSIST_GRID;
@@ -335,16 +324,10 @@ int forward_impl(const T *params, const T *cubes, long n, int z, T *probs, int *
         }
         CCNN_LAUNCH_CHECK();
         {
-            ProfileScope prof_("fc1_partial", st);
-            fc1_partial<T><<<dim3(nch, (nr + 15) / 16), 256, fc1_smem<T>(), st>>>(params + d.off_w1, w.pool,
-                                                                                nr, d.pout, w.z1part);
-        }
-        CCNN_LAUNCH_CHECK();
-        {
-            ProfileScope prof_("head", st);
-            head<T><<<pg, 128, 0, st>>>(params, d.off_b1, d.off_w2, d.off_b2, w.z1part, nch, nr, nullptr,
-                                        nullptr, nullptr, nullptr, probs ? probs + s0 * O : nullptr,
-                                        argmax ? argmax + s0 : nullptr, nullptr);
+            ProfileScope prof_("fc_head_fwd", st);
+            fc_head_fwd<T><<<(nr + FH_MS - 1) / FH_MS, 256, FcHeadLds<T>::bytes, st>>>(
+                params, d.off_w1, d.off_b1, d.off_w2, d.off_b2, w.pool, nr, d.pout,
+                probs ? probs + s0 * O : nullptr, argmax ? argmax + s0 : nullptr);
         }
         CCNN_LAUNCH_CHECK();
     }
