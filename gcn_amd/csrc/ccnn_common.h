@@ -72,7 +72,15 @@ inline int allow_smem(Kern k, size_t bytes)
 
 #ifdef __HIPCC__
 // tanh in the reference's spelling (gcn_mbgd_fp64.cu:233): 2/(1+1/exp(2v)) - 1.
-__device__ __forceinline__ float act(float v) { return 2.0f / (1.0f + (1.0f / expf(2.0f * v))) - 1.0f; }
+// fp32: same expression on the hardware exp2 / reciprocal units (v_exp_f32, v_rcp_f32, ~1 ulp
+// each) instead of the ~50-instruction correctly-rounded expf and two IEEE divisions; the
+// activation epilogue otherwise costs more than half of the conv MFMA time.  Saturates like the
+// reference: exp -> inf gives 1, exp -> 0 gives -1.
+__device__ __forceinline__ float act(float v)
+{
+    const float e = __builtin_amdgcn_exp2f(v * 2.885390081777927f);   // exp(2v) = 2^(2v log2 e)
+    return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_rcpf(e)) - 1.0f;
+}
 __device__ __forceinline__ double act(double v) { return 2.0 / (1.0 + (1.0 / exp(2.0 * v))) - 1.0; }
 __device__ __forceinline__ float rexp(float v) { return expf(v); }
 __device__ __forceinline__ double rexp(double v) { return exp(v); }

@@ -200,23 +200,74 @@ __device__ __forceinline__ T reduce_scatter16(T (&v)[16], int lane)
 }
 
 // ---------------------------------------------------------------------------
-// Conv forward tiles for one LDS-resident sample: a0[f][t] = tanh*(sum_k wl[f][k] cube[18 t + k] + b0[f]).
-// The [re x 171] x [171 x 20] product is ceil(re/16) x 2 MFMA tiles; wave w takes
-// position tiles w, w+4, ... with both filter halves, so each A fragment feeds two
-// MFMAs.  A comes straight from the cube (window t starts at 18 t: no im2col).
-// wl is [32][LDW0] with rows 20..31 and taps 171..174 zero; cube is zero-padded to
-// conv_cube_pad(re); a0 rows have stride lda.
-template <typename T>
-__device__ __forceinline__ void conv_fwd_tiles(const T *cube, const T *wl, T *a0, int lda, int re,
-                                               T bias0, T bias1, int lane, int wave)
+// tanh + max-pool of one 16-position conv tile straight from the MFMA accumulators
+// (window 2, clipped at re, strict '<' so the first maximum wins,
+// gcn_mbgd_fp64.cu:237-268).  Position pairs (2m, 2m+1) never straddle a tile (tiles
+// start at multiples of 16).  In the f32 C/D map a lane holds rows 4q..4q+3, so both
+// members of a pair are in the same lane; in the f64 map it holds rows q, q+4, q+8,
+// q+12 and the partner row lives in lane^16.  put(f, m, value, winning position).
+template <typename Put>
+__device__ __forceinline__ void pool_tile(const Mma<float>::acc_t &acc, float bias, int f, bool fvalid, int t0,
+                                          int re, int lane, Put put)
+{
+    const int q = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; r += 2) {
+        const int t = t0 + 4 * q + r;
+        if (fvalid && t < re) {
+            float best = act(acc[r] + bias);
+            int bt = t;
+            if (t + 1 < re) {
+                const float vn = act(acc[r + 1] + bias);
+                if (best < vn) {
+                    best = vn;
+                    bt = t + 1;
+                }
+            }
+            put(f, t >> 1, best, bt);
+        }
+    }
+}
+template <typename Put>
+__device__ __forceinline__ void pool_tile(const Mma<double>::acc_t &acc, double bias, int f, bool fvalid, int t0,
+                                          int re, int lane, Put put)
+{
+    const int q = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int t = t0 + q + 4 * r;
+        const double v = act(acc[r] + bias);
+        const double vn = __shfl_xor(v, 16);     // row q^1 of the same column
+        if (fvalid && !(q & 1) && t < re) {
+            double best = v;
+            int bt = t;
+            if (t + 1 < re && best < vn) {
+                best = vn;
+                bt = t + 1;
+            }
+            put(f, t >> 1, best, bt);
+        }
+    }
+}
+
+// Conv forward + tanh + pool for LDS-resident samples: per sample the
+// [re x 171] x [171 x 20] product is ceil(re/16) x 2 MFMA tiles.  The nsamp x ceil(re/16)
+// position tiles are dealt round-robin to the 4 waves; each tile runs both filter halves so
+// an A fragment feeds two MFMAs.  A comes straight from the cube (window t starts at 18 t:
+// no im2col).  wl is [32][LDW0] with rows 20..31 and taps 171..174 zero; every cube is
+// zero-padded to conv_cube_pad(re) and they are cube_stride apart.
+// put(sample, f, m, value, winning position).
+template <typename T, typename Put>
+__device__ __forceinline__ void conv_pool_tiles(const T *cube, int cube_stride, int nsamp, const T *wl, int re,
+                                                T bias0, T bias1, int lane, int wave, Put put)
 {
     const int col = lane & 15, kq = lane >> 4;
-    const int f1 = 16 + col;
     const int mt = conv_mtiles(re);
-    for (int tile = wave; tile < mt; tile += 4) {
-        const T *ap = cube + WSTEP * (tile * 16 + col) + kq;
-        const T *bp0 = wl + col * LDW0 + kq;
-        const T *bp1 = wl + f1 * LDW0 + kq;
+    const T *bp0 = wl + col * LDW0 + kq;
+    const T *bp1 = wl + (16 + col) * LDW0 + kq;
+    for (int job = wave; job < nsamp * mt; job += 4) {
+        const int sidx = job / mt, tile = job - sidx * mt;
+        const T *ap = cube + sidx * cube_stride + WSTEP * (tile * 16 + col) + kq;
         typename Mma<T>::acc_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
         int s = 0;
         for (; s + 4 <= KSTEPS0; s += 4) {   // operands of four k-steps in flight
@@ -238,14 +289,9 @@ __device__ __forceinline__ void conv_fwd_tiles(const T *cube, const T *wl, T *a0
             acc0 = Mma<T>::mma(a, bp0[4 * s], acc0);
             acc1 = Mma<T>::mma(a, bp1[4 * s], acc1);
         }
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int t = tile * 16 + Mma<T>::row(lane, r);
-            if (t < re) {
-                a0[col * lda + t] = act(acc0[r] + bias0);
-                if (f1 < F) a0[f1 * lda + t] = act(acc1[r] + bias1);
-            }
-        }
+        auto put1 = [&](int f, int m, T v, int bt) { put(sidx, f, m, v, bt); };
+        pool_tile(acc0, bias0, col, true, tile * 16, re, lane, put1);
+        pool_tile(acc1, bias1, 16 + col, 16 + col < F, tile * 16, re, lane, put1);
     }
 }
 
@@ -261,27 +307,6 @@ __device__ __forceinline__ void stage_filters(const T *__restrict__ w0, T *wl, i
         const int f = e / K, k = e - f * K;
         wl[f * LDW0 + (FLIP ? K - 1 - k : k)] = v;
     });
-}
-
-// Max-pool (window 2, clipped, strict '<' so the first maximum wins,
-// gcn_mbgd_fp64.cu:237-268) of a0[F][lda]; put(o, value, winning position).
-template <typename T, typename Put>
-__device__ __forceinline__ void pool_rows(const T *a0, int lda, int re, int mre, int tid, Put put)
-{
-    for (int o = tid; o < F * mre; o += 256) {
-        const int f = o / mre, m = o - f * mre;
-        const int t = 2 * m;
-        T best = a0[f * lda + t];
-        int bt = t;
-        if (t + 1 < re) {
-            const T vn = a0[f * lda + t + 1];
-            if (best < vn) {
-                best = vn;
-                bt = t + 1;
-            }
-        }
-        put(o, best, bt);
-    }
 }
 
 }  // namespace ccnn

@@ -33,45 +33,90 @@ int raise_smem_limit(const void *fn, size_t bytes)
 }
 
 // ---------------------------------------------------------------------------
-// convolution + tanh + max-pool, one sample at a time per workgroup (grid-stride
-// over samples; the filters are staged once per workgroup).
+// convolution + tanh + max-pool.  A workgroup takes SPI (2 or 4) samples per
+// iteration (grid-stride over such groups; the filters are staged once): the
+// SPI x ceil(re/16) position tiles are dealt round-robin to the 4 waves so every
+// wave has the same number of MFMA chains, and the next group's cubes are loaded
+// into registers while the current group's MFMAs run.
 // pool[row][f*mre + m] = pooled value.
-template <typename T, bool FLIP>
+constexpr int CONV_MAXREG = 32;   // cube elements a thread may hold in flight for the next group
+
+// NREG (8, 16, 24 or 32) >= ceil(SPI*cube_len/256) is a template parameter so that the
+// prefetch is straight-line code: loads under a run-time guard are waited for at the
+// guard's join, which would put the whole memory latency back in front of the MFMAs.
+template <typename T, bool FLIP, int SPI, int NREG>
 __global__ __launch_bounds__(256) void conv_pool_fwd(const T *__restrict__ params,
                                                      const T *__restrict__ cubes, long first, int nrows,
                                                      int cube_len, int re, int mre, int off_b0,
                                                      T *__restrict__ pool)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int RPS = NREG / SPI;                 // prefetch registers per sample
     const int cube_pad = conv_cube_pad(re);
-    const int lda = odd_up(re);
-    T *cube = reinterpret_cast<T *>(smem);
-    T *wl = cube + cube_pad;
-    T *a0 = wl + 32 * LDW0;
+    T *cube = reinterpret_cast<T *>(smem);          // [SPI][cube_pad]
+    T *wl = cube + SPI * cube_pad;
+    T *pl = wl + 32 * LDW0;                          // [SPI][pout] pooled values of the group
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15;
     const int pout = F * mre;
+    const long ngroups = ((long)nrows + SPI - 1) / SPI;
 
-    for (int e = cube_len + tid; e < cube_pad; e += 256) cube[e] = 0;
+    for (int e = tid; e < SPI * cube_pad; e += 256) cube[e] = 0;   // pads stay zero: loads only touch [0, cube_len)
     stage_filters<T, FLIP>(params, wl, tid);
     const T bias0 = params[off_b0 + col];
-    const T bias1 = 16 + col < F ? params[off_b0 + 16 + col] : T(0);
+    const T bias1 = params[off_b0 + min(16 + col, F - 1)];
 
-    for (long row = blockIdx.x; row < nrows; row += gridDim.x) {
-        __syncthreads();   // everyone is done with the previous sample's cube and a0
-        stage<8, 256>(cubes + (first + row) * (long)cube_len, cube_len, tid, [&](int e, T v) { cube[e] = v; });
-        __syncthreads();
-        conv_fwd_tiles<T>(cube, wl, a0, lda, re, bias0, bias1, lane, wave);
-        __syncthreads();
-        T *dst = pool + row * pout;
-        pool_rows<T>(a0, lda, re, mre, tid, [&](int o, T v, int) { dst[o] = v; });
+    T creg[NREG];
+    auto issue = [&](long g) {   // next group's cubes -> registers (clamped, unconditional)
+#pragma unroll
+        for (int si = 0; si < SPI; si++) {
+            const long r = g * SPI + si < nrows ? g * SPI + si : (long)nrows - 1;
+            const T *src = cubes + (first + r) * (long)cube_len;
+#pragma unroll
+            for (int u = 0; u < RPS; u++) creg[si * RPS + u] = src[min(u * 256 + tid, cube_len - 1)];
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int si = 0; si < SPI; si++)
+#pragma unroll
+            for (int u = 0; u < RPS; u++) {
+                const int e = u * 256 + tid;
+                if (e < cube_len) cube[si * cube_pad + e] = creg[si * RPS + u];
+            }
+    };
+
+    long g = blockIdx.x;
+    if (g < ngroups) issue(g);
+    __syncthreads();
+    if (g < ngroups) commit();
+    for (; g < ngroups; g += gridDim.x) {
+        __syncthreads();                                   // this group's cubes are in LDS; pl is free
+        const long gn = g + gridDim.x;
+        if (gn < ngroups) issue(gn);                       // next group's loads fly during the MFMAs
+        conv_pool_tiles<T>(cube, cube_pad, SPI, wl, re, bias0, bias1, lane, wave,
+                           [&](int si, int f, int m, T v, int) { pl[si * pout + f * mre + m] = v; });
+        __syncthreads();                                   // pooled values complete, cubes no longer read
+        if (gn < ngroups) commit();
+        const int ns = (int)(((long)nrows - g * SPI) < SPI ? ((long)nrows - g * SPI) : SPI);
+        T *dst = pool + (g * SPI) * pout;
+        for (int o = tid; o < ns * pout; o += 256) dst[o] = pl[o];
     }
 }
 
 template <typename T>
-size_t conv_smem(const ccnn_dims_t &d)
+size_t conv_smem(const ccnn_dims_t &d, int spi)
 {
-    return (size_t)(conv_cube_pad(d.re) + 32 * LDW0 + F * odd_up(d.re)) * sizeof(T);
+    return (size_t)(spi * conv_cube_pad(d.re) + 32 * LDW0 + spi * d.pout) * sizeof(T);
+}
+
+// Samples per iteration: 4 when their cubes fit the per-thread prefetch registers and
+// the LDS budget leaves room for a second workgroup per CU, else 2.
+template <typename T>
+int conv_spi(const ccnn_dims_t &d)
+{
+    const bool fits4 = 4 * ((d.cube + 255) / 256) <= CONV_MAXREG && conv_smem<T>(d, 4) <= 80 * 1024;
+    return fits4 ? 4 : 2;
 }
 
 // ---------------------------------------------------------------------------
@@ -312,15 +357,27 @@ int forward_impl(const T *params, const T *cubes, long n, int z, T *probs, int *
     const long rows = n < FWD_CHUNK ? n : FWD_CHUNK;
     if (ws_bytes < FwdWs<T>::bytes(rows, d)) return CCNN_E_WORKSPACE;
     FwdWs<T> w(ws, rows, d);
-    if (int e = allow_smem(conv_pool_fwd<T, FLIP>, conv_smem<T>(d))) return e;
+    const int spi = conv_spi<T>(d);
+    const int nreg8 = (spi * ((d.cube + 255) / 256) + 7) / 8;   // prefetch registers per thread, in eights
+    if (nreg8 > CONV_MAXREG / 8) return CCNN_E_RANGE;
+    const size_t csm = conv_smem<T>(d, spi);
+    typedef void (*ConvKern)(const T *, const T *, long, int, int, int, int, int, T *);
+    static const ConvKern kern[2][4] = {
+        {conv_pool_fwd<T, FLIP, 2, 8>, conv_pool_fwd<T, FLIP, 2, 16>, conv_pool_fwd<T, FLIP, 2, 24>,
+         conv_pool_fwd<T, FLIP, 2, 32>},
+        {conv_pool_fwd<T, FLIP, 4, 8>, conv_pool_fwd<T, FLIP, 4, 16>, conv_pool_fwd<T, FLIP, 4, 24>,
+         conv_pool_fwd<T, FLIP, 4, 32>}};
+    const ConvKern conv = kern[spi == 4][nreg8 - 1];
+    if (int e = allow_smem(conv, csm)) return e;
     if (int e = allow_smem(fc_head_fwd<T>, FcHeadLds<T>::bytes)) return e;
     for (long s0 = 0; s0 < n; s0 += rows) {
         const int nr = (int)((n - s0) < rows ? (n - s0) : rows);
-        const int pg = nr < PERSIST_GRID ? nr : PERSIST_GRID;
+        const int groups = (nr + spi - 1) / spi;
+        const int pg = groups < PERSIST_GRID ? groups : PERSIST_GRID;
         {
             ProfileScope prof_("conv_pool_fwd", st);
-            conv_pool_fwd<T, FLIP><<<pg, 256, conv_smem<T>(d), st>>>(params, cubes, s0, nr, d.cube, d.re,
-                                                                    d.mre, d.off_b0, w.pool);
+            hipLaunchKernelGGL(conv, dim3(pg), dim3(256), csm, st, params, cubes, s0, nr, d.cube, d.re, d.mre,
+                               d.off_b0, w.pool);
         }
         CCNN_LAUNCH_CHECK();
         {

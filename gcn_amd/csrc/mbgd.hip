@@ -44,7 +44,7 @@ __host__ __device__ inline FusedLayout fused_layout(int re, int mre)
     L.ks = (re + 3) >> 2;
     L.ldd = stride15(4 * L.ks);
     const int wl_len = 32 * (L.ldd > LDW0 ? L.ldd : LDW0);   // filters, later the scattered deltas
-    const int a0_len = F * odd_up(re) > 8 * H ? F * odd_up(re) : 8 * H;   // conv outputs, later FC1 partial sums
+    const int a0_len = 8 * H;   // FC1 partial sums [G][100]
     int o = 0;
     L.cube = o; o += up4(conv_cube_pad(re));
     L.wl = o;   o += up4(wl_len);
@@ -149,7 +149,6 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15;
     const int re = d.re, mre = d.mre, pout = d.pout;
-    const int lda = odd_up(re);
     const long row = blockIdx.x;
     const int *lab = onehot + (first + row) * O;
 
@@ -193,20 +192,15 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
 #if CCNN_STOP_PHASE == 1
     return;
 #endif
-    conv_fwd_tiles<T>(cube, wl, a0, lda, re, bias0, bias1, lane, wave);
+    conv_pool_tiles<T>(cube, 0, 1, wl, re, bias0, bias1, lane, wave, [&](int, int f, int m, T v, int bt) {
+        pl[f * mre + m] = v;
+        px[f * mre + m] = bt;
+    });
     __syncthreads();
 #if CCNN_STOP_PHASE == 2
     return;
 #endif
-    {
-        T *dst = pool_g + row * pout;
-        pool_rows<T>(a0, lda, re, mre, tid, [&](int o, T v, int bt) {
-            pl[o] = v;
-            px[o] = bt;
-            dst[o] = v;
-        });
-    }
-    __syncthreads();
+    for (int o = tid; o < pout; o += 256) pool_g[row * pout + o] = pl[o];
 
     // ---- FC1 forward: z1[n] = sum_p pool[p] W1[n + 100 p] ---------------------------
     // 16-byte vectors along n; QL lanes per W1 row (25 or 50 of them active), G row groups.
