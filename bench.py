@@ -33,17 +33,34 @@ SEED_BASE = 20240
 WORKLOAD_CONFIG = {"ksc": 2, "indian_pines": 3, "pavia_u": 4, "aviris": 5}
 
 
-def kernel_work(d, B):
-    """Algorithmic FLOPs (or bytes) per launch of each training kernel."""
+def kernel_work(d, z):
+    """Algorithmic FLOPs (or bytes) per PIXEL of each kernel (update: per launch)."""
     conv = 2.0 * 171 * d.re * 20
     fc1 = 2.0 * d.pout * 100
     return {
         # conv fwd + conv bwd, FC1 fwd + delta, FC2 fwd + delta
-        "sample_fwd_bwd": ("mfma", B * (2 * conv + 2 * fc1 + 4.0 * 1300)),
+        "sample_fwd_bwd": ("mfma", 2 * conv + 2 * fc1 + 4.0 * 1300),
         # dW1 = pool^T d1, dW2 = a1^T d2
-        "grad_reduce": ("mfma", B * (fc1 + 2.0 * 1300)),
-        "update_f32_kernel": ("hbm", 3.0 * d.nparams * 4),
+        "grad_reduce": ("mfma", fc1 + 2.0 * 1300),
+        "conv_pool_fwd": ("mfma", conv),
+        "fc_head_fwd": ("mfma", fc1 + 2.0 * 1300),
+        # 9z values read + 9z written + 9 int32 indices
+        "gather_tile": ("hbm", 2.0 * 9 * z * 4 + 36),
+        "update_f32_kernel": ("hbm", None),
     }
+
+
+def committed_traffic(workload, batch, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc cannot
+    run inside this process); None when no pass was recorded for this workload and batch."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            for rec in json.load(f)["records"]:
+                if (rec["workload"], rec["batch"], rec["kernel"]) == (workload, batch, kernel):
+                    return rec["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
 
 
 def main():
@@ -55,6 +72,8 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="samples per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N>1 step (gradient, all-reduce, update) even with one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -65,7 +84,13 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
         args.gpus = world
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     L.load()
 
@@ -100,7 +125,7 @@ def main():
 
     def step(i):
         b = i % nb
-        if world == 1:
+        if not use_dist:
             # gradient + update fused (nothing has to happen in between on one GPU)
             ops.mbgd_step(params, cubes, onehot_d, b * B, B, z, lr, loss_values=loss_ring[b], workspace=ws)
         else:
@@ -109,7 +134,7 @@ def main():
             ops.update(params, grad, lr, z)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -144,7 +169,8 @@ def main():
         dti = t.item()
     infer_pps = world * te_n * reps / dti
 
-    # ---- per-kernel timing of the same steps (HIP events on the launch stream)
+    # ---- per-kernel timing (HIP events on the launch stream, recorded inside the library):
+    # the same training steps, one inference pass and one gather of the training list
     roof = None
     kernels = {}
     if rank == 0:
@@ -154,25 +180,44 @@ def main():
         step(i)
     fence()
     if rank == 0:
+        preps = 5
+        gws = ops.Workspace(dev)
+        idx_d = torch.from_numpy(tr9[lo:lo + slice_len]).to(dev)
+        for _ in range(preps):
+            ops.forward(params, tcubes, z, want_probs=False, workspace=fws)
+            ops.gather(scene_d, idx_d, x, y, z, out=cubes, workspace=gws)
+        torch.cuda.synchronize()
         L.profile_enable(False)
         rep = L.profile_report()
-        work = kernel_work(d, B)
+        work = kernel_work(d, z)
+        pixels = {"sample_fwd_bwd": B, "grad_reduce": B, "conv_pool_fwd": te_n, "fc_head_fwd": te_n,
+                  "gather_tile": slice_len}
+        # what an event bracket adds to a record, measured by the library on empty brackets
+        ems, ecnt = rep.get("(empty event pair)", (0.0, 0))
+        bracket_ms = ems / ecnt if ecnt else 0.0
         for name, (ms, cnt) in rep.items():
             if name not in work or cnt == 0:
                 continue
-            bound, units = work[name]
-            avg_s = ms / cnt * 1e-3
+            ms = max(ms - bracket_ms * cnt, 1e-9)
+            bound, per_px = work[name]
+            # FWD_CHUNK-sized launches: a pass over te_n pixels may be several launches
+            passes = preps if name in ("conv_pool_fwd", "fc_head_fwd", "gather_tile") else cnt
+            units = 3.0 * d.nparams * 4 * cnt if per_px is None else per_px * pixels[name] * passes
+            tot_s = ms * 1e-3
             if bound == "mfma":
-                ach, peak, unit = units / avg_s / 1e12, PEAK_FP32_MATRIX_TFLOPS, "TFLOP/s"
+                ach, peak, unit = units / tot_s / 1e12, PEAK_FP32_MATRIX_TFLOPS, "TFLOP/s"
             else:
-                ach, peak, unit = units / avg_s / 1e9, PEAK_HBM_GBS, "GB/s"
-            kernels[name] = {"avg_us": round(avg_s * 1e6, 3), "launches": cnt, "bound": bound,
+                ach, peak, unit = units / tot_s / 1e9, PEAK_HBM_GBS, "GB/s"
+            kernels[name] = {"avg_us": round(ms / cnt * 1e3, 3), "launches": cnt, "bound": bound,
                              "achieved": round(ach, 4), "peak": peak, "unit": unit, "frac": round(ach / peak, 5)}
-        if kernels:
-            dom = max(kernels, key=lambda k: kernels[k]["avg_us"])
+        train_k = [k for k in ("sample_fwd_bwd", "grad_reduce", "update_f32_kernel") if k in kernels]
+        if train_k:
+            dom = max(train_k, key=lambda k: kernels[k]["avg_us"])
             k = kernels[dom]
             roof = {"kernel": dom, "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"],
-                    "unit": k["unit"], "frac": k["frac"], "traffic": None, "avg_us": k["avg_us"]}
+                    "unit": k["unit"], "frac": k["frac"],
+                    "traffic": committed_traffic(args.workload, B, dom), "avg_us": k["avg_us"],
+                    "event_bracket_us": round(bracket_ms * 1e3, 3)}
 
     # ---- CPU baseline: the oracle's fp32 minibatch step on the host cores (rank 0, N=1 only)
     cpu = None

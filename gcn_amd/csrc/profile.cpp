@@ -19,6 +19,7 @@ namespace {
 struct Record {
     const char *name;
     hipEvent_t start, stop;
+    bool owns_start;
 };
 std::mutex g_mu;
 std::vector<Record> g_records;
@@ -52,7 +53,12 @@ void profile_end(hipStream_t st)
     std::lock_guard<std::mutex> lk(g_mu);
     hipEvent_t stop = get_event();
     (void)hipEventRecord(stop, st);
-    g_records.push_back({g_open_name, g_open_start, stop});
+    g_records.push_back({g_open_name, g_open_start, stop, true});
+    // A back-to-back pair with nothing in between measures what the bracketing itself adds
+    // to every record; the caller subtracts it.
+    hipEvent_t again = get_event();
+    (void)hipEventRecord(again, st);
+    g_records.push_back({CCNN_PROFILE_EMPTY_PAIR, stop, again, false});
 }
 
 }  // namespace ccnn
@@ -82,7 +88,7 @@ int ccnn_profile_report(int index, char *name, int name_len, double *total_ms, l
                 a.first += ms;
                 a.second += 1;
             }
-            g_free.push_back(r.start);
+            if (r.owns_start) g_free.push_back(r.start);
             g_free.push_back(r.stop);
         }
         g_records.clear();

@@ -224,8 +224,11 @@ int ccnn_host_partition(long n_train, int batch, int n_ranks, int rank, long ste
  * kernel launch of this library is bracketed by two HIP events on its own
  * stream.  ccnn_profile_report(i, ...) returns 1 and the i-th kernel's name,
  * summed milliseconds and launch count, 0 past the end; index 0 first waits for
- * and folds in all launches recorded so far.  Process-wide state; meant for
- * bench.py, leave disabled otherwise. */
+ * and folds in all launches recorded so far.  Each bracket is followed by an
+ * empty bracket reported under CCNN_PROFILE_EMPTY_PAIR: its average is what the
+ * bracketing adds to every record and is to be subtracted from each average.
+ * Process-wide state; meant for bench.py, leave disabled otherwise. */
+#define CCNN_PROFILE_EMPTY_PAIR "(empty event pair)"
 int ccnn_profile_enable(int on);
 int ccnn_profile_report(int index, char *name, int name_len, double *total_ms, long *launches);
 
