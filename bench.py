@@ -192,13 +192,9 @@ def main():
         work = kernel_work(d, z)
         pixels = {"sample_fwd_bwd": B, "grad_reduce": B, "conv_pool_fwd": te_n, "fc_head_fwd": te_n,
                   "gather_tile": slice_len}
-        # what an event bracket adds to a record, measured by the library on empty brackets
-        ems, ecnt = rep.get("(empty event pair)", (0.0, 0))
-        bracket_ms = ems / ecnt if ecnt else 0.0
         for name, (ms, cnt) in rep.items():
             if name not in work or cnt == 0:
                 continue
-            ms = max(ms - bracket_ms * cnt, 1e-9)
             bound, per_px = work[name]
             # FWD_CHUNK-sized launches: a pass over te_n pixels may be several launches
             passes = preps if name in ("conv_pool_fwd", "fc_head_fwd", "gather_tile") else cnt
@@ -216,8 +212,7 @@ def main():
             k = kernels[dom]
             roof = {"kernel": dom, "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"],
                     "unit": k["unit"], "frac": k["frac"],
-                    "traffic": committed_traffic(args.workload, B, dom), "avg_us": k["avg_us"],
-                    "event_bracket_us": round(bracket_ms * 1e3, 3)}
+                    "traffic": committed_traffic(args.workload, B, dom), "avg_us": k["avg_us"]}
 
     # ---- CPU baseline: the oracle's fp32 minibatch step on the host cores (rank 0, N=1 only)
     cpu = None

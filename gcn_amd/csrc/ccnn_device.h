@@ -34,7 +34,12 @@ struct Mma<double> {
 // LDS row strides.  A stride of 15 (mod 32) elements lets 16 lanes that walk rows
 // and the 16 lanes one element further hit distinct banks (one pair excepted); 16
 // (mod 32) does the same for lanes that walk columns of two adjacent rows.
-constexpr int LDW0 = 175;   // conv filters   [F][175], 171 taps + zero pad
+constexpr int LDWK = 16;    // conv filters: two tap-major tiles [172 taps][16 filters].  Lanes (col, kq)
+                            // read tap 4s+kq, filter col: 16 kq + col covers all 32 banks once per
+                            // half-wave (a filter-major [f][175] tile costs a 2-way conflict per read).
+constexpr int WL_TILE = 172 * LDWK;  // tap 171 and filters 20..31 are zero
+constexpr int WL_LEN = 2 * WL_TILE;
+__host__ __device__ inline int wl_index(int f, int k) { return (f >> 4) * WL_TILE + k * LDWK + (f & 15); }
 constexpr int LDW1 = 112;   // W1 chunk       [64 p][112], fc1_partial (lanes walk n)
 constexpr int LDP = 79;     // pool tile      [16 b][79]
 constexpr int LDW2 = 111;   // W1 chunk       [64 p][111], fc1_bwd_delta (lanes walk p)
@@ -254,7 +259,7 @@ __device__ __forceinline__ void pool_tile(const Mma<double>::acc_t &acc, double 
 // [re x 171] x [171 x 20] product is ceil(re/16) x 2 MFMA tiles.  The nsamp x ceil(re/16)
 // position tiles are dealt round-robin to the 4 waves; each tile runs both filter halves so
 // an A fragment feeds two MFMAs.  A comes straight from the cube (window t starts at 18 t:
-// no im2col).  wl is [32][LDW0] with rows 20..31 and taps 171..174 zero; every cube is
+// no im2col).  wl holds the two tap-major filter tiles [172][LDWK]; every cube is
 // zero-padded to conv_cube_pad(re) and they are cube_stride apart.
 // put(sample, f, m, value, winning position).
 template <typename T, typename Put>
@@ -263,8 +268,8 @@ __device__ __forceinline__ void conv_pool_tiles(const T *cube, int cube_stride, 
 {
     const int col = lane & 15, kq = lane >> 4;
     const int mt = conv_mtiles(re);
-    const T *bp0 = wl + col * LDW0 + kq;
-    const T *bp1 = wl + (16 + col) * LDW0 + kq;
+    const T *bp0 = wl + kq * LDWK + col;
+    const T *bp1 = bp0 + WL_TILE;
     for (int job = wave; job < nsamp * mt; job += 4) {
         const int sidx = job / mt, tile = job - sidx * mt;
         const T *ap = cube + sidx * cube_stride + WSTEP * (tile * 16 + col) + kq;
@@ -275,8 +280,8 @@ __device__ __forceinline__ void conv_pool_tiles(const T *cube, int cube_stride, 
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 a[u] = ap[4 * (s + u)];
-                b0[u] = bp0[4 * (s + u)];
-                b1[u] = bp1[4 * (s + u)];
+                b0[u] = bp0[4 * (s + u) * LDWK];
+                b1[u] = bp1[4 * (s + u) * LDWK];
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -286,8 +291,8 @@ __device__ __forceinline__ void conv_pool_tiles(const T *cube, int cube_stride, 
         }
         for (; s < KSTEPS0; s++) {
             const T a = ap[4 * s];
-            acc0 = Mma<T>::mma(a, bp0[4 * s], acc0);
-            acc1 = Mma<T>::mma(a, bp1[4 * s], acc1);
+            acc0 = Mma<T>::mma(a, bp0[4 * s * LDWK], acc0);
+            acc1 = Mma<T>::mma(a, bp1[4 * s * LDWK], acc1);
         }
         auto put1 = [&](int f, int m, T v, int bt) { put(sidx, f, m, v, bt); };
         pool_tile(acc0, bias0, col, true, tile * 16, re, lane, put1);
@@ -295,17 +300,17 @@ __device__ __forceinline__ void conv_pool_tiles(const T *cube, int cube_stride, 
     }
 }
 
-// Stages the 20 x 171 filters into wl[32][LDW0] (zero rows/taps included).  The
+// Stages the 20 x 171 filters into the two wl[172][LDWK] tiles (zero taps/filters included).  The
 // fp32 reference walks the filter backwards in the forward pass only
 // (gcn_mbgd_fp32.cu:241-243): FLIP stores tap k at 170-k.  Needs a barrier after.
 template <typename T, bool FLIP>
 __device__ __forceinline__ void stage_filters(const T *__restrict__ w0, T *wl, int tid)
 {
-    for (int e = tid; e < 32 * LDW0; e += 256) wl[e] = 0;
+    for (int e = tid; e < WL_LEN; e += 256) wl[e] = 0;
     __syncthreads();
     stage<7, 256>(w0, F * K, tid, [&](int e, T v) {
         const int f = e / K, k = e - f * K;
-        wl[f * LDW0 + (FLIP ? K - 1 - k : k)] = v;
+        wl[wl_index(f, FLIP ? K - 1 - k : k)] = v;
     });
 }
 

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void conv_pool_fwd(const T *__restrict__ param
     const int cube_pad = conv_cube_pad(re);
     T *cube = reinterpret_cast<T *>(smem);          // [SPI][cube_pad]
     T *wl = cube + SPI * cube_pad;
-    T *pl = wl + 32 * LDW0;                          // [SPI][pout] pooled values of the group
+    T *pl = wl + WL_LEN;                          // [SPI][pout] pooled values of the group
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15;
     const int pout = F * mre;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void conv_pool_fwd(const T *__restrict__ param
 template <typename T>
 size_t conv_smem(const ccnn_dims_t &d, int spi)
 {
-    return (size_t)(spi * conv_cube_pad(d.re) + 32 * LDW0 + spi * d.pout) * sizeof(T);
+    return (size_t)(spi * conv_cube_pad(d.re) + WL_LEN + spi * d.pout) * sizeof(T);
 }
 
 // Samples per iteration: 4 when their cubes fit the per-thread prefetch registers and
@@ -375,16 +375,14 @@ int forward_impl(const T *params, const T *cubes, long n, int z, T *probs, int *
         const int groups = (nr + spi - 1) / spi;
         const int pg = groups < PERSIST_GRID ? groups : PERSIST_GRID;
         {
-            ProfileScope prof_("conv_pool_fwd", st);
-            hipLaunchKernelGGL(conv, dim3(pg), dim3(256), csm, st, params, cubes, s0, nr, d.cube, d.re, d.mre,
-                               d.off_b0, w.pool);
+            launch("conv_pool_fwd", conv, dim3(pg), dim3(256), csm, st, params, cubes, s0, nr, d.cube, d.re, d.mre,
+                   d.off_b0, w.pool);
         }
         CCNN_LAUNCH_CHECK();
         {
-            ProfileScope prof_("fc_head_fwd", st);
-            fc_head_fwd<T><<<(nr + FH_MS - 1) / FH_MS, 256, FcHeadLds<T>::bytes, st>>>(
-                params, d.off_w1, d.off_b1, d.off_w2, d.off_b2, w.pool, nr, d.pout,
-                probs ? probs + s0 * O : nullptr, argmax ? argmax + s0 : nullptr);
+            launch("fc_head_fwd", fc_head_fwd<T>, dim3((nr + FH_MS - 1) / FH_MS), dim3(256), FcHeadLds<T>::bytes, st,
+                   params, d.off_w1, d.off_b1, d.off_w2, d.off_b2, w.pool, nr, d.pout,
+                   probs ? probs + s0 * O : nullptr, argmax ? argmax + s0 : nullptr);
         }
         CCNN_LAUNCH_CHECK();
     }
@@ -429,8 +427,8 @@ int ccnn_count_correct(const int *argmax, const int *labels, long n, int *count,
     long blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     {
-        ProfileScope prof_("count_correct_kernel", st);
-        count_correct_kernel<<<(int)blocks, 256, 0, st>>>(argmax, labels, n, count);
+        launch("count_correct_kernel", count_correct_kernel, dim3((unsigned)blocks), dim3(256), 0, st, argmax, labels, n,
+               count);
     }
     CCNN_LAUNCH_CHECK();
     return 0;
@@ -441,8 +439,8 @@ int ccnn_update_f64(double *params, const double *grad, double lr, int divisor, 
     if (!params || !grad || divisor <= 0 || n < 0) return CCNN_E_INVALID;
     if (n == 0) return 0;
     {
-        ProfileScope prof_("update_f64_kernel", (hipStream_t)stream);
-        update_f64_kernel<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(params, grad, lr, divisor, n);
+        launch("update_f64_kernel", update_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+               (hipStream_t)stream, params, grad, lr, divisor, n);
     }
     CCNN_LAUNCH_CHECK();
     return 0;
@@ -454,9 +452,8 @@ int ccnn_update_f32(float *params, const float *grad, float lr, int z, int freez
     if (make_dims(z, &d) || !params || !grad) return CCNN_E_INVALID;
     const int lo = freeze_conv_bias ? d.off_b0 : 0, hi = freeze_conv_bias ? d.off_w1 : 0;
     {
-        ProfileScope prof_("update_f32_kernel", (hipStream_t)stream);
-        update_f32_kernel<<<(d.nparams + 255) / 256, 256, 0, (hipStream_t)stream>>>(params, grad, lr, d.nparams,
-                                                                                   lo, hi);
+        launch("update_f32_kernel", update_f32_kernel, dim3((d.nparams + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+               params, grad, lr, d.nparams, lo, hi);
     }
     CCNN_LAUNCH_CHECK();
     return 0;
@@ -468,9 +465,8 @@ int ccnn_update_adagrad_f64(double *params, double *rms, const double *grad, dou
     if (!params || !rms || !grad || iter <= 0 || n < 0) return CCNN_E_INVALID;
     if (n == 0) return 0;
     {
-        ProfileScope prof_("update_adagrad_f64_kernel", (hipStream_t)stream);
-        update_adagrad_f64_kernel<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(params, rms, grad, lr,
-                                                                                          iter, n);
+        launch("update_adagrad_f64_kernel", update_adagrad_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+               (hipStream_t)stream, params, rms, grad, lr, iter, n);
     }
     CCNN_LAUNCH_CHECK();
     return 0;

@@ -127,8 +127,8 @@ int gather_impl(const T *scene, const int *idx9, long n, int x, int y, int z, T 
         if (ws_bytes < GatherWs::bytes(n)) return CCNN_E_WORKSPACE;
         GatherWs w(ws, n);
         {
-            ProfileScope prof_("gather_keys", st);
-            gather_keys<<<(int)((n + 255) / 256), 256, 0, st>>>(idx9, n, w.keys, w.vals);
+            launch("gather_keys", gather_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, idx9, n, w.keys,
+                   w.vals);
         }
         CCNN_LAUNCH_CHECK();
         unsigned bits = 1;
@@ -141,9 +141,8 @@ int gather_impl(const T *scene, const int *idx9, long n, int x, int y, int z, T 
     long blocks = (n + GS - 1) / GS;
     if (blocks > 8192) blocks = 8192;
     {
-        ProfileScope prof_("gather_tile", st);
-        gather_tile<T><<<dim3((unsigned)blocks, (unsigned)((z + GBANDS - 1) / GBANDS)), 256, 0, st>>>(
-            scene, idx9, order, n, (long)x * y, z, out);
+        launch("gather_tile", gather_tile<T>, dim3((unsigned)blocks, (unsigned)((z + GBANDS - 1) / GBANDS)), dim3(256), 0,
+               st, scene, idx9, order, n, (long)x * y, z, out);
     }
     CCNN_LAUNCH_CHECK();
     return 0;

@@ -42,8 +42,8 @@ __host__ __device__ inline FusedLayout fused_layout(int re, int mre)
     FusedLayout L;
     const int pout = F * mre;
     L.ks = (re + 3) >> 2;
-    L.ldd = stride15(4 * L.ks);
-    const int wl_len = 32 * (L.ldd > LDW0 ? L.ldd : LDW0);   // filters, later the scattered deltas
+    L.ldd = 4 * L.ks * LDWK;   // one position-major delta tile [4 ks][16 filters]
+    const int wl_len = 2 * L.ldd > WL_LEN ? 2 * L.ldd : WL_LEN;   // filters, later the scattered deltas
     const int a0_len = 8 * H;   // FC1 partial sums [G][100]
     int o = 0;
     L.cube = o; o += up4(conv_cube_pad(re));
@@ -67,14 +67,16 @@ __host__ __device__ inline FusedLayout fused_layout(int re, int mre)
 // Conv weight gradient of one sample as an MFMA product:
 // dW0[f][tap] = sum_t delta[f][t] cube[18 t + tap] / re  ([20 x re] x [re x 171]),
 // 2 filter tiles x 11 tap tiles, wave w owns tap tiles w, w+4, w+8.
-// delta is [32][ldd] (rows 20..31 zero), cube zero-padded; out = [F][K].
+// delta is two position-major tiles [4 ks][16] (tile_len apart; filters 20..31 and positions
+// >= re zero) so that, like the forward filter tiles, A-fragment reads are bank-conflict free;
+// cube zero-padded; out = [F][K].
 template <typename T>
-__device__ __forceinline__ void conv_bwd_tiles(const T *cube, const T *delta, int ldd, int ks, int re,
+__device__ __forceinline__ void conv_bwd_tiles(const T *cube, const T *delta, int tile_len, int ks, int re,
                                                T *__restrict__ out, int lane, int wave)
 {
     const int col = lane & 15, kq = lane >> 4;
-    const T *ap0 = delta + col * ldd + kq;
-    const T *ap1 = delta + (16 + col) * ldd + kq;
+    const T *ap0 = delta + kq * LDWK + col;
+    const T *ap1 = ap0 + tile_len;
     const bool t2 = wave + 8 < 11;   // 171 taps = 11 tiles
     const T *bp0 = cube + WSTEP * kq + wave * 16 + col;
     const T *bp1 = bp0 + 64;
@@ -85,8 +87,8 @@ __device__ __forceinline__ void conv_bwd_tiles(const T *cube, const T *delta, in
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             if (u < n) {
-                a0[u] = ap0[4 * (s + u)];
-                a1[u] = ap1[4 * (s + u)];
+                a0[u] = ap0[4 * (s + u) * LDWK];
+                a1[u] = ap1[4 * (s + u) * LDWK];
                 b0[u] = bp0[4 * (s + u) * WSTEP];
                 b1[u] = bp1[4 * (s + u) * WSTEP];
                 b2[u] = bp2[4 * (s + u) * WSTEP];
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
     const T bias0 = params[d.off_b0 + col];
     const T bias1 = params[d.off_b0 + min(16 + col, F - 1)];
     for (int e = d.cube + tid; e < conv_cube_pad(re); e += 256) cube[e] = 0;
-    for (int e = tid; e < 32 * LDW0; e += 256) wl[e] = 0;
+    for (int e = tid; e < WL_LEN; e += 256) wl[e] = 0;
     stage<8, 256>(cubes + (first + row) * (long)d.cube, d.cube, tid, [&](int e, T v) { cube[e] = v; });
     __syncthreads();
 #pragma unroll
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
         if (e < F * K) {
             const int f = e / K, k = e - f * K;
             // the fp32 reference walks the filter backwards in the forward pass (gcn_mbgd_fp32.cu:241-243)
-            wl[f * LDW0 + (FLIP ? K - 1 - k : k)] = wreg[u];
+            wl[wl_index(f, FLIP ? K - 1 - k : k)] = wreg[u];
         }
     }
     __syncthreads();
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
         loss_terms(p, lab[tid], &lta[tid], &ltb[tid]);
     }
     // the filters are dead: clear their region for the scattered deltas
-    for (int e = tid; e < 32 * L.ldd; e += 256) wl[e] = 0;
+    for (int e = tid; e < 2 * L.ldd; e += 256) wl[e] = 0;
     __syncthreads();
     if (tid == 255) loss_values[row] = loss_sum(lta, ltb, lab);
     if (tid < H) {
@@ -326,7 +328,8 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
                 const T pv = pl[p];
                 const T dv = tot * (1 + pv) * (1 - pv);
                 dp[p] = dv;
-                delta[(p / mre) * L.ldd + px[p]] = dv;
+                const int f = p / mre;
+                delta[(f >> 4) * L.ldd + px[p] * LDWK + (f & 15)] = dv;
             }
         }
     }
@@ -521,20 +524,17 @@ int mbgd_impl(const T *params, const T *cubes, const int *onehot, long first, in
     const FusedLayout L = fused_layout<T>(d.re, d.mre);
     if (int e = allow_smem(sample_fwd_bwd<T, FLIP>, L.bytes)) return e;
     {
-        ProfileScope prof_("sample_fwd_bwd", st);
-        sample_fwd_bwd<T, FLIP><<<B, 256, L.bytes, st>>>(params, cubes, onehot, first, d, w.pool, w.a1, w.d1,
-                                                        w.d2, probs, loss_values, w.slab);
+        launch("sample_fwd_bwd", sample_fwd_bwd<T, FLIP>, dim3(B), dim3(256), L.bytes, st, params, cubes, onehot, first,
+               d, w.pool, w.a1, w.d1, w.d2, probs, loss_values, w.slab);
     }
     CCNN_LAUNCH_CHECK();
     const int nb_w1 = (d.pout + 15) / 16;
     const int nb_w0 = (F * K + F + 63) / 64;
     const int nb_w2 = (H * O + 63) / 64;
     {
-        ProfileScope prof_("grad_reduce", st);
-        grad_reduce<T><<<nb_w1 + nb_w0 + nb_w2 + 3, GR_THREADS, 0, st>>>(B, d.pout, d.off_w1, d.off_b1,
-                                                                         d.off_w2, d.off_b2, w.pool, w.a1,
-                                                                         w.d1, w.d2, w.slab, nb_w1, nb_w0,
-                                                                         nb_w2, grad, upd);
+        launch("grad_reduce", grad_reduce<T>, dim3(nb_w1 + nb_w0 + nb_w2 + 3), dim3(GR_THREADS), 0, st, B, d.pout,
+               d.off_w1, d.off_b1, d.off_w2, d.off_b2, w.pool, w.a1, w.d1, w.d2, w.slab, nb_w1, nb_w0, nb_w2, grad,
+               upd);
     }
     CCNN_LAUNCH_CHECK();
     return 0;

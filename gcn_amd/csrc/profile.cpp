@@ -1,6 +1,6 @@
 // Per-kernel timing for bench.py's roofline figure: every launch made while
-// timing is enabled is bracketed by two HIP events recorded on the launch's own
-// stream; ccnn_profile_report() sums the elapsed times per kernel name.
+// timing is enabled carries a HIP event pair on its own stream;
+// ccnn_profile_report() sums the elapsed times per kernel name.
 #include "profile.h"
 
 #include <cstring>
@@ -19,13 +19,10 @@ namespace {
 struct Record {
     const char *name;
     hipEvent_t start, stop;
-    bool owns_start;
 };
 std::mutex g_mu;
 std::vector<Record> g_records;
 std::vector<hipEvent_t> g_free;
-const char *g_open_name = nullptr;
-hipEvent_t g_open_start;
 
 hipEvent_t get_event()
 {
@@ -40,25 +37,17 @@ hipEvent_t get_event()
 }
 }  // namespace
 
-void profile_begin(const char *name, hipStream_t st)
+void profile_events(hipEvent_t *start, hipEvent_t *stop)
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    g_open_name = name;
-    g_open_start = get_event();
-    (void)hipEventRecord(g_open_start, st);
+    *start = get_event();
+    *stop = get_event();
 }
 
-void profile_end(hipStream_t st)
+void profile_push(const char *name, hipEvent_t start, hipEvent_t stop)
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    hipEvent_t stop = get_event();
-    (void)hipEventRecord(stop, st);
-    g_records.push_back({g_open_name, g_open_start, stop, true});
-    // A back-to-back pair with nothing in between measures what the bracketing itself adds
-    // to every record; the caller subtracts it.
-    hipEvent_t again = get_event();
-    (void)hipEventRecord(again, st);
-    g_records.push_back({CCNN_PROFILE_EMPTY_PAIR, stop, again, false});
+    g_records.push_back({name, start, stop});
 }
 
 }  // namespace ccnn
@@ -88,7 +77,7 @@ int ccnn_profile_report(int index, char *name, int name_len, double *total_ms, l
                 a.first += ms;
                 a.second += 1;
             }
-            if (r.owns_start) g_free.push_back(r.start);
+            g_free.push_back(r.start);
             g_free.push_back(r.stop);
         }
         g_records.clear();

@@ -243,24 +243,21 @@ int ccnn_sgd_f64(double *params, const double *cubes, const int *onehot, long fi
         const long s = first + i;
         const double *cube = cubes + s * (long)d.cube;
         {
-            ProfileScope prof_("sgd_fwd", st);
-            sgd_fwd<<<F, 256, smem_f, st>>>(params, cube, d.cube, d.re, d.mre, d.off_b0, d.off_w1, d.off_b1,
-                                        d.off_w2, d.off_b2, lr, i > 0, ws);
+            launch("sgd_fwd", sgd_fwd, dim3(F), dim3(256), smem_f, st, params, cube, d.cube, d.re, d.mre, d.off_b0,
+                   d.off_w1, d.off_b1, d.off_w2, d.off_b2, lr, i > 0, ws);
         }
         CCNN_LAUNCH_CHECK();
         {
-            ProfileScope prof_("sgd_bwd", st);
-            sgd_bwd<<<F, 256, smem_b, st>>>(params, cube, onehot + s * O, d.cube, d.re, d.mre, d.off_b0,
-                                        d.off_w1, d.off_b1, d.off_w2, d.off_b2, lr, s == 0, loss, ws);
+            launch("sgd_bwd", sgd_bwd, dim3(F), dim3(256), smem_b, st, params, cube, onehot + s * O, d.cube, d.re, d.mre,
+                   d.off_b0, d.off_w1, d.off_b1, d.off_w2, d.off_b2, lr, s == 0, loss, ws);
         }
         CCNN_LAUNCH_CHECK();
     }
     if (count > 0) {
         // flush the last sample's pending head update
         {
-            ProfileScope prof_("sgd_fwd", st);
-            sgd_fwd<<<F, 256, smem_f, st>>>(params, nullptr, d.cube, d.re, d.mre, d.off_b0, d.off_w1, d.off_b1,
-                                        d.off_w2, d.off_b2, lr, 1, ws);
+            launch("sgd_fwd", sgd_fwd, dim3(F), dim3(256), smem_f, st, params, (const double *)nullptr, d.cube, d.re,
+                   d.mre, d.off_b0, d.off_w1, d.off_b1, d.off_w2, d.off_b2, lr, 1, ws);
         }
         CCNN_LAUNCH_CHECK();
     }

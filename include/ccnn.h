@@ -221,14 +221,11 @@ int ccnn_host_partition(long n_train, int batch, int n_ranks, int rank, long ste
 
 
 /* Measurement hooks (no counterpart in the reference).  While enabled, every
- * kernel launch of this library is bracketed by two HIP events on its own
- * stream.  ccnn_profile_report(i, ...) returns 1 and the i-th kernel's name,
+ * kernel launch of this library carries a start/stop HIP event pair on its own
+ * stream (attached to the dispatch, so the interval is the kernel's own).  ccnn_profile_report(i, ...) returns 1 and the i-th kernel's name,
  * summed milliseconds and launch count, 0 past the end; index 0 first waits for
- * and folds in all launches recorded so far.  Each bracket is followed by an
- * empty bracket reported under CCNN_PROFILE_EMPTY_PAIR: its average is what the
- * bracketing adds to every record and is to be subtracted from each average.
- * Process-wide state; meant for bench.py, leave disabled otherwise. */
-#define CCNN_PROFILE_EMPTY_PAIR "(empty event pair)"
+ * and folds in all launches recorded so far.  Process-wide state; meant for
+ * bench.py, leave disabled otherwise. */
 int ccnn_profile_enable(int on);
 int ccnn_profile_report(int index, char *name, int name_len, double *total_ms, long *launches);
 
