@@ -20,11 +20,23 @@
 #include "ccnn_common.h"
 #include "profile.h"
 
+#ifndef CCNN_GATHER_PROBE
+#define CCNN_GATHER_PROBE 0   // diagnostics: 1 = skip the stores, 2 = skip the scene loads
+#endif
+
 namespace ccnn {
 
-constexpr int GS = 16;   // samples per workgroup
-constexpr int GBANDS = 32;   // bands per LDS pass
+#ifndef CCNN_GATHER_GSH
+#define CCNN_GATHER_GSH 4
+#endif
+constexpr int GSH = CCNN_GATHER_GSH;
+constexpr int GS = 1 << GSH;   // samples per workgroup
+constexpr int GBANDS = 512 / GS;   // bands per LDS pass
 constexpr int GU = GS * GBANDS * NB / 256;   // loads in flight per thread (18)
+#ifndef CCNN_GATHER_GRID
+#define CCNN_GATHER_GRID 1024
+#endif
+constexpr int GATHER_GRID = CCNN_GATHER_GRID;   // persistent workgroups (4 per CU)
 
 template <typename T>
 __global__ __launch_bounds__(256) void gather_tile(const T *__restrict__ scene,
@@ -32,48 +44,117 @@ __global__ __launch_bounds__(256) void gather_tile(const T *__restrict__ scene,
                                                    const int *__restrict__ order, long n, long plane,
                                                    int z, T *__restrict__ out)
 {
-    // grid: x = group of 16 samples (grid-stride), y = pass of 32 bands
-    __shared__ int sidx[NB * GS];            // [j][s] pixel index
-    __shared__ long sid[GS];                 // output row of sample s
+    // A workgroup walks groups of 16 samples and, per group, passes of 32 bands.
+    // The walk is software-pipelined: the scene loads of the next (group, pass) item are issued
+    // into registers, and the pixel indices of the next group are fetched, before the current
+    // item's tile is stored, so a workgroup always has reads and writes in flight together.
+    __shared__ int sidx[2][NB * GS];         // [j][s] pixel index, double-buffered by group
+    __shared__ long sid[2][GS];              // output row of sample s
     __shared__ T tile[GS][GBANDS * NB + 1];  // odd row stride: lanes walking s hit distinct banks
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long cube_len = (long)NB * z;
     const long ngroups = (n + GS - 1) / GS;
-    const int b0 = blockIdx.y * GBANDS;
-    const int nb = (z - b0) < GBANDS ? (z - b0) : GBANDS;
-    const int items = nb * NB * GS;
-    const int row_len = nb * NB;
-    for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        const long s0 = g * GS;
-        const int ns = (int)((n - s0) < GS ? (n - s0) : GS);
-        __syncthreads();   // the previous group's readers of sid/sidx/tile are done
-        if (tid < NB * GS) {
-            const int s = tid / NB, j = tid - s * NB;
-            const long k = s0 + (s < ns ? s : ns - 1);
-            const long id = order ? order[k] : k;
-            sidx[j * GS + s] = idx9[id * NB + j];
-            if (j == 0) sid[s] = id;
+    const int npass = (z + GBANDS - 1) / GBANDS;
+    // Consecutive workgroup ids land on different XCDs, each with its own L2.  Every XCD gets one
+    // contiguous eighth of the (centre-ordered) group list and its workgroups sweep it side by
+    // side (workgroup w takes groups w, w + gstep, ..), so the scene rows a group shares with the
+    // groups above and below it are fetched once, into one L2, while they are still resident.
+    const long chunk = (ngroups + 7) / 8;
+    const int xcd = blockIdx.x & 7;
+    const long gstep = gridDim.x >> 3;   // the grid is a multiple of 8
+    long g = xcd * chunk + (blockIdx.x >> 3);
+    const long gend = (xcd + 1) * chunk < ngroups ? (xcd + 1) * chunk : ngroups;
+    if (g >= gend) return;
+    // short lists: gridDim.y workgroups share a group, each taking a contiguous range of passes
+    const int p_lo = (int)((long)blockIdx.y * npass / gridDim.y), p_hi = (int)((long)(blockIdx.y + 1) * npass / gridDim.y);
+    if (p_lo >= p_hi) return;
+    int pass = p_lo;
+
+    constexpr int IL = (NB * GS + 255) / 256;   // index values a thread fetches per group
+    auto load_idx = [&](long grp, int *iv, long *id) {   // clamped, unconditional
+        const long gc = grp < ngroups ? grp : ngroups - 1;
+#pragma unroll
+        for (int u = 0; u < IL; u++) {
+            const int e = min(u * 256 + tid, NB * GS - 1);
+            const int is = e / NB, ij = e - is * NB;
+            const long k = gc * GS + is;
+            const long kk = k < n ? k : n - 1;
+            id[u] = order ? order[kk] : kk;
+            iv[u] = idx9[id[u] * NB + ij];
         }
-        __syncthreads();
-        T tmp[GU];
+    };
+    auto publish_idx = [&](int b, const int *iv, const long *id) {
+#pragma unroll
+        for (int u = 0; u < IL; u++) {
+            const int e = u * 256 + tid;
+            if (e < NB * GS) {
+                const int is = e / NB, ij = e - is * NB;
+                sidx[b][ij * GS + is] = iv[u];
+                if (ij == 0) sid[b][is] = id[u];
+            }
+        }
+    };
+    T tmp[GU];
+    auto issue = [&](int buf, int pass) {   // scene loads of one item -> registers (clamped, unconditional)
+        const int b0 = pass * GBANDS;
+        const int nb = (z - b0) < GBANDS ? (z - b0) : GBANDS;
+        const int items = nb * NB * GS;
 #pragma unroll
         for (int u = 0; u < GU; u++) {
-            // clamped and unconditional: a guarded load costs a full memory round trip each
             const int w = min(u * 256 + tid, items - 1);
-            const int s = w & (GS - 1), bj = w >> 4;
+            const int s = w & (GS - 1), bj = w >> GSH;
             const int bb = bj / NB, jj = bj - bb * NB;
-            tmp[u] = scene[sidx[jj * GS + s] + (b0 + bb) * plane];
+#if CCNN_GATHER_PROBE == 2
+            tmp[u] = (T)sidx[buf][jj * GS + s];
+#else
+            tmp[u] = scene[sidx[buf][jj * GS + s] + (b0 + bb) * plane];
+#endif
         }
+    };
+
+    int iv[IL];
+    long id[IL];
+    load_idx(g, iv, id);
+    publish_idx(0, iv, id);
+    __syncthreads();
+    issue(0, pass);
+    load_idx(g + gstep, iv, id);   // next group's indices, published when this group's last pass is stored
+    int buf = 0;
+    while (true) {
+        const int b0 = pass * GBANDS;
+        const int nb = (z - b0) < GBANDS ? (z - b0) : GBANDS;
+        const int items = nb * NB * GS, row_len = nb * NB;
+        const int ns = (int)((n - g * GS) < GS ? (n - g * GS) : GS);
 #pragma unroll
         for (int u = 0; u < GU; u++) {
             const int w = u * 256 + tid;
-            if (w < items) tile[w & (GS - 1)][w >> 4] = tmp[u];
+            if (w < items) tile[w & (GS - 1)][w >> GSH] = tmp[u];
         }
+        const bool new_group = pass + 1 == p_hi;   // the next item starts this workgroup's next group
+        const bool more = !new_group || g + gstep < gend;
+        if (new_group) publish_idx(buf ^ 1, iv, id);
         __syncthreads();
-        for (int e = tid; e < GS * row_len; e += 256) {
-            const int s = e / row_len, k = e - s * row_len;
-            if (s < ns) out[sid[s] * cube_len + (long)b0 * NB + k] = tile[s][k];
+        // next item's loads (when there is none, the current item's addresses again: harmless)
+        const int nbuf = more && new_group ? buf ^ 1 : buf;
+        const int npas = more ? (new_group ? p_lo : pass + 1) : pass;
+        issue(nbuf, npas);
+        if (new_group) load_idx(g + 2 * gstep, iv, id);
+        // store the tile: wave w owns samples w, w+4, ..; lanes walk the sample's contiguous run
+        for (int s = wave; s < ns; s += 4) {
+            T *dst = out + sid[buf][s] * cube_len + (long)b0 * NB;
+            for (int k = lane; k < row_len; k += 64) {
+#if CCNN_GATHER_PROBE == 1
+                if (tile[s][k] == (T)-12345.678) dst[k] = tile[s][k];
+#else
+                dst[k] = tile[s][k];
+#endif
+            }
         }
+        if (!more) break;
+        __syncthreads();   // the tile's readers are done before the next item overwrites it
+        if (new_group) g += gstep;
+        buf = nbuf;
+        pass = npas;
     }
 }
 
@@ -138,11 +219,14 @@ int gather_impl(const T *scene, const int *idx9, long n, int x, int y, int z, T 
         if (e != hipSuccess) return (int)e;
         order = w.order;
     }
-    long blocks = (n + GS - 1) / GS;
-    if (blocks > 8192) blocks = 8192;
+    long blocks = ((n + GS - 1) / GS + 7) / 8 * 8;   // a multiple of 8: one slice of the list per XCD
+    if (blocks > GATHER_GRID) blocks = GATHER_GRID;
+    const int npass = (z + GBANDS - 1) / GBANDS;
+    long split = 3 * GATHER_GRID / (2 * blocks);   // enough workgroups to fill the chip on short lists
+    split = split < 1 ? 1 : split > npass ? npass : split;
     {
-        launch("gather_tile", gather_tile<T>, dim3((unsigned)blocks, (unsigned)((z + GBANDS - 1) / GBANDS)), dim3(256), 0,
-               st, scene, idx9, order, n, (long)x * y, z, out);
+        launch("gather_tile", gather_tile<T>, dim3((unsigned)blocks, (unsigned)split), dim3(256), 0, st, scene, idx9,
+               order, n, (long)x * y, z, out);
     }
     CCNN_LAUNCH_CHECK();
     return 0;
