@@ -169,6 +169,24 @@ def main():
         dti = t.item()
     infer_pps = world * te_n * reps / dti
 
+    # ---- fp64 per-sample SGD on the same cubes (sequential by definition: replicas only, rank 0 reports)
+    sgd_pps = None
+    if rank == 0:
+        ns = min(slice_len, 4096)
+        cubes64 = cubes[:ns].double()
+        oh64 = onehot_d[:ns].contiguous()
+        p64 = torch.from_numpy(prep.init_params(z, np.float64)).to(dev)
+        sloss = torch.zeros(1, dtype=torch.float64, device=dev)
+        sws = ops.Workspace(dev)
+        ops.sgd(p64, cubes64, oh64, 0, min(ns, 256), z, 0.008, sloss, workspace=sws)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        ops.sgd(p64, cubes64, oh64, 0, ns, z, 0.008, sloss, workspace=sws)
+        torch.cuda.synchronize()
+        sgd_pps = ns / (time.perf_counter() - t2)
+        assert torch.isfinite(p64).all()
+        del cubes64, p64
+
     # ---- per-kernel timing (HIP events on the launch stream, recorded inside the library):
     # the same training steps, one inference pass and one gather of the training list
     roof = None
@@ -249,6 +267,7 @@ def main():
             "config": {"workload": f"{args.workload}-shaped {x}x{y}x{z} fp32 MBGD", "batch_per_gpu": B,
                        "global_batch": B * world, "train_pixels": T, "parallelism": f"dp{world}"},
             "infer_pixels_per_s": round(infer_pps, 1),
+            "sgd_fp64_pixels_per_s": round(sgd_pps, 1),
             "roofline": roof,
             "cpu_baseline": cpu,
             "kernels": kernels,
