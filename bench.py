@@ -46,7 +46,10 @@ def kernel_work(d, z):
         "fc_head_fwd": ("mfma", fc1 + 2.0 * 1300),
         # 9z values read + 9z written + 9 int32 indices
         "gather_tile": ("hbm", 2.0 * 9 * z * 4 + 36),
+        # per launch: read params, read gradient, write params
         "update_f32_kernel": ("hbm", None),
+        # per launch (filled in by the caller): the same plus world slots written and read
+        "allreduce_apply": ("hbm", None),
     }
 
 
@@ -123,6 +126,21 @@ def main():
     ws = ops.Workspace(dev)
     lr = 0.04 / world      # plain-sum update: keep the step size independent of the global batch
 
+    # N>1: the library's one-shot exchange over xGMI, fused with the update; RCCL if it cannot be
+    # set up on this node or fails its self-test against RCCL (CCNN_ALLREDUCE=rccl forces RCCL)
+    comm = None
+    if use_dist and os.environ.get("CCNN_ALLREDUCE", "oneshot") != "rccl":
+        from gcn_amd.comm import NodeComm
+        try:
+            comm = NodeComm(d.nparams, torch.float32)
+            if not comm.self_test(rounds=2):
+                comm.close()
+                comm = None
+        except Exception as e:   # raised on every rank alike (see NodeComm)
+            if rank == 0:
+                print(f"one-shot exchange unavailable ({e}); using RCCL", file=sys.stderr)
+            comm = None
+
     def step(i):
         b = i % nb
         if not use_dist:
@@ -130,8 +148,11 @@ def main():
             ops.mbgd_step(params, cubes, onehot_d, b * B, B, z, lr, loss_values=loss_ring[b], workspace=ws)
         else:
             ops.mbgd_grad(params, cubes, onehot_d, b * B, B, z, grad=grad, loss_values=loss_ring[b], workspace=ws)
-            dist.all_reduce(grad)
-            ops.update(params, grad, lr, z)
+            if comm is not None:
+                comm.allreduce_update(params, grad, lr, z)
+            else:
+                dist.all_reduce(grad)
+                ops.update(params, grad, lr, z)
 
     def fence():
         if use_dist:
@@ -152,6 +173,15 @@ def main():
         dt = t.item()
     train_pps = world * B * args.steps / dt
     assert torch.isfinite(params).all(), "training diverged"
+    replicas_identical = True
+    if use_dist:
+        # every rank applied the same sums in the same order: the replicas must agree bit for bit
+        digest = params.view(torch.int32).to(torch.int64).sum().reshape(1)
+        every = [torch.empty_like(digest) for _ in range(world)]
+        dist.all_gather(every, digest)
+        replicas_identical = all(bool(torch.equal(every[0], e)) for e in every)
+        if comm is not None:
+            assert comm.status() == 0, "a rank gave up waiting for a peer during the exchange"
 
     # ---- inference over this rank's test pixels
     fws = ops.Workspace(dev)
@@ -216,7 +246,8 @@ def main():
             bound, per_px = work[name]
             # FWD_CHUNK-sized launches: a pass over te_n pixels may be several launches
             passes = preps if name in ("conv_pool_fwd", "fc_head_fwd", "gather_tile") else cnt
-            units = 3.0 * d.nparams * 4 * cnt if per_px is None else per_px * pixels[name] * passes
+            per_launch = (3.0 + (2.0 * world if name == "allreduce_apply" else 0.0)) * d.nparams * 4
+            units = per_launch * cnt if per_px is None else per_px * pixels[name] * passes
             tot_s = ms * 1e-3
             if bound == "mfma":
                 ach, peak, unit = units / tot_s / 1e12, PEAK_FP32_MATRIX_TFLOPS, "TFLOP/s"
@@ -224,7 +255,7 @@ def main():
                 ach, peak, unit = units / tot_s / 1e9, PEAK_HBM_GBS, "GB/s"
             kernels[name] = {"avg_us": round(ms / cnt * 1e3, 3), "launches": cnt, "bound": bound,
                              "achieved": round(ach, 4), "peak": peak, "unit": unit, "frac": round(ach / peak, 5)}
-        train_k = [k for k in ("sample_fwd_bwd", "grad_reduce", "update_f32_kernel") if k in kernels]
+        train_k = [k for k in ("sample_fwd_bwd", "grad_reduce", "update_f32_kernel", "allreduce_apply") if k in kernels]
         if train_k:
             dom = max(train_k, key=lambda k: kernels[k]["avg_us"])
             k = kernels[dom]
@@ -265,7 +296,10 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}-shaped {x}x{y}x{z} fp32 MBGD", "batch_per_gpu": B,
-                       "global_batch": B * world, "train_pixels": T, "parallelism": f"dp{world}"},
+                       "global_batch": B * world, "train_pixels": T, "parallelism": f"dp{world}",
+                       "exchange": ("none" if not use_dist else "xgmi one-shot all-reduce fused with update"
+                                    if comm is not None else "rccl all-reduce + update"),
+                       "replicas_identical": replicas_identical},
             "infer_pixels_per_s": round(infer_pps, 1),
             "sgd_fp64_pixels_per_s": round(sgd_pps, 1),
             "roofline": roof,
@@ -273,7 +307,9 @@ def main():
             "kernels": kernels,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if comm is not None:
+        comm.close()
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -1,0 +1,304 @@
+// One-shot all-reduce of the flat gradient across the GPUs of one node, fused with the
+// weight update (replaces the host-staged broadcast / slab gather / master update of
+// hyper_version_mGPU_MBGD.cu:962-978, 1093-1171).
+//
+// The message is small (46 853 .. 108 853 values), so the exchange is latency-bound and a
+// ring's 2(n-1) hops are the wrong shape.  Every rank owns an exchange buffer that its peers
+// map (IPC handle between processes, or the pointer itself inside one process); in ONE kernel
+// a workgroup takes a 4 KB chunk of the vector and
+//   1. writes its chunk of the local gradient into slot [rank] of every peer's buffer over
+//      xGMI (all links busy at once, one hop),
+//   2. makes the writes visible (system-scope fence) and raises flag [rank][chunk] at every peer,
+//   3. waits until its own flags [0..n)[chunk] show this call's sequence number,
+//   4. adds the n slots in rank order - the same order on every rank, so all ranks compute
+//      bit-identical sums - and applies the update rule to its chunk of the parameters.
+// Chunks are independent, so there is no grid-wide barrier.  Slots and flags are double-buffered
+// by call parity: a rank can only start call k+2 after every peer raised its flags of call k+1,
+// which each peer did after its kernel of call k (the last reader of that parity) had finished.
+// The buffers are uncached (fine-grained) device memory: peers' writes bypass the local L2,
+// so must the local reads.
+#include <cstdlib>
+#include <new>
+
+#include "ccnn_common.h"
+#include "profile.h"
+
+namespace ccnn {
+
+constexpr int COMM_MAX_RANKS = 16;
+constexpr int COMM_CHUNK_BYTES = 4096;                      // per workgroup: 256 threads x 16 bytes
+constexpr unsigned long long COMM_SPIN_TICKS = 1000000000ull;   // default wait limit: 10 s of the 100 MHz wall clock
+
+struct CommDev {            // passed to the kernel by value
+    char *peer[COMM_MAX_RANKS];   // every rank's exchange buffer as mapped here ([rank] = the local one)
+    int world, rank;
+    long slot_bytes;              // bytes of one [parity][rank] slot
+    long flags_off, status_off;   // byte offsets inside a buffer
+    int nchunks;
+    unsigned long long spin_ticks;   // how long a workgroup waits for a peer before it gives up
+};
+
+}  // namespace ccnn
+
+struct ccnn_comm {
+    ccnn::CommDev dev;
+    int device;
+    long max_elems;
+    int elem;
+    size_t total_bytes;
+    bool opened[ccnn::COMM_MAX_RANKS];
+    unsigned step;
+};
+
+namespace ccnn {
+
+typedef unsigned long long u64;
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+
+struct RulePlain {   // buf[e] = sum
+    template <typename T>
+    __device__ void operator()(T *p, long e, T sum) const { p[e] = sum; }
+};
+template <typename T>
+struct RuleSgd {     // params[e] -= lr * sum / divisor, elements in [lo, hi) untouched
+    T lr;
+    T divisor;
+    long lo, hi;
+    __device__ void operator()(T *p, long e, T sum) const
+    {
+        if (e >= lo && e < hi) return;
+        p[e] = p[e] - lr * sum / divisor;
+    }
+};
+template <>
+struct RuleSgd<float> {   // fp32 variant: plain sum, no division (gcn_mbgd_fp32.cu:1031-1059)
+    float lr;
+    float divisor;
+    long lo, hi;
+    __device__ void operator()(float *p, long e, float sum) const
+    {
+        if (e >= lo && e < hi) return;
+        p[e] = p[e] - lr * sum;
+    }
+};
+
+template <typename T, typename Rule>
+__global__ __launch_bounds__(256) void allreduce_apply(T *target, const T *src, long n,   // may alias (in-place sum)
+                                                       CommDev c, unsigned step, Rule rule)
+{
+    constexpr int VW = 16 / sizeof(T);
+    constexpr int CH = COMM_CHUNK_BYTES / sizeof(T);
+    typedef T Vec __attribute__((ext_vector_type(16 / sizeof(T))));
+    const int tid = threadIdx.x, chunk = blockIdx.x;
+    const int par = step & 1;
+    const long e0 = (long)chunk * CH + (long)tid * VW;
+    const long slot_off = (long)chunk * COMM_CHUNK_BYTES + (long)tid * 16;
+
+    // 1. this rank's chunk -> slot [par][rank] of every peer (clamped, unconditional load; tail lanes
+    //    carry copies that nobody reads back)
+    Vec v;
+#pragma unroll
+    for (int j = 0; j < VW; j++) v[j] = src[min(e0 + j, n - 1)];
+    for (int k = 0; k < c.world; k++) {
+        const int r = (c.rank + 1 + k) % c.world;   // start at the next rank: spreads the first writes over the links
+        char *slot = c.peer[r] + ((long)par * c.world + c.rank) * c.slot_bytes;
+        *reinterpret_cast<Vec *>(slot + slot_off) = v;
+    }
+    // 2. publish: every thread's writes are visible system-wide before any flag goes up
+    __threadfence_system();
+    __syncthreads();
+    if (tid < c.world) {
+        unsigned *flag = reinterpret_cast<unsigned *>(c.peer[tid] + c.flags_off) +
+                         ((long)par * c.world + c.rank) * c.nchunks + chunk;
+        __hip_atomic_store(flag, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // 3. wait for every rank's chunk
+    char *mine = c.peer[c.rank];
+    unsigned *status = reinterpret_cast<unsigned *>(mine + c.status_off);
+    if (tid < c.world) {
+        const unsigned *flag = reinterpret_cast<const unsigned *>(mine + c.flags_off) +
+                               ((long)par * c.world + tid) * c.nchunks + chunk;
+        const u64 t0 = wall_clock64();
+        unsigned spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != step) {
+            // all ranks run this kernel for the same call, so the wait ends; the limit bounds the
+            // damage if a peer process died
+            if ((++spins & 1023) == 0 &&
+                (wall_clock64() - t0 > c.spin_ticks ||
+                 __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))) {
+                __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);   // system scope: nothing below is served from a stale cache
+    // 4. sum in rank order, apply
+    T sum[VW];
+#pragma unroll
+    for (int j = 0; j < VW; j++) sum[j] = 0;
+    for (int r = 0; r < c.world; r++) {
+        const u64 *slot = reinterpret_cast<const u64 *>(mine + ((long)par * c.world + r) * c.slot_bytes + slot_off);
+        union {
+            u64 w[2];
+            T t[VW];
+        } u;
+        u.w[0] = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        u.w[1] = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+        for (int j = 0; j < VW; j++) sum[j] = sum[j] + u.t[j];
+    }
+#pragma unroll
+    for (int j = 0; j < VW; j++)
+        if (e0 + j < n) rule(target, e0 + j, sum[j]);
+}
+
+template <typename T, typename Rule>
+int allreduce_launch(ccnn_comm *cm, T *target, const T *src, long n, Rule rule, void *stream)
+{
+    if (!cm || !target || !src || n <= 0) return CCNN_E_INVALID;
+    if ((int)sizeof(T) != cm->elem || n > cm->max_elems) return CCNN_E_RANGE;
+    for (int r = 0; r < cm->dev.world; r++)
+        if (!cm->dev.peer[r]) return CCNN_E_INVALID;   // not connected
+    constexpr int CH = COMM_CHUNK_BYTES / sizeof(T);
+    const int chunks = (int)((n + CH - 1) / CH);
+    cm->step++;
+    if (cm->step == 0) cm->step = 1;   // 0 is the flags' initial value
+    launch("allreduce_apply", allreduce_apply<T, Rule>, dim3(chunks), dim3(256), 0, (hipStream_t)stream, target, src,
+           n, cm->dev, cm->step, rule);
+    CCNN_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace ccnn
+
+using namespace ccnn;
+
+extern "C" {
+
+int ccnn_comm_create(int world, int rank, long max_elems, int elem_size, ccnn_comm_t **comm, void *handle)
+{
+    if (!comm || !handle || world < 1 || world > COMM_MAX_RANKS || rank < 0 || rank >= world || max_elems <= 0 ||
+        (elem_size != 4 && elem_size != 8))
+        return CCNN_E_INVALID;
+    static_assert(sizeof(hipIpcMemHandle_t) == CCNN_COMM_HANDLE_BYTES, "handle size");
+    ccnn_comm *cm = new (std::nothrow) ccnn_comm();
+    if (!cm) return (int)hipErrorOutOfMemory;
+    cm->max_elems = max_elems;
+    cm->elem = elem_size;
+    cm->step = 0;
+    CommDev &d = cm->dev;
+    d.world = world;
+    d.rank = rank;
+    d.spin_ticks = COMM_SPIN_TICKS;
+    if (const char *ms = getenv("CCNN_COMM_WAIT_MS")) {   // tests shorten the limit
+        const long v = atol(ms);
+        if (v > 0) d.spin_ticks = (unsigned long long)v * 100000ull;
+    }
+    d.nchunks = (int)(((size_t)max_elems * elem_size + COMM_CHUNK_BYTES - 1) / COMM_CHUNK_BYTES);
+    d.slot_bytes = (long)d.nchunks * COMM_CHUNK_BYTES;
+    d.flags_off = 2L * world * d.slot_bytes;
+    d.status_off = d.flags_off + (long)align_up((size_t)2 * world * d.nchunks * sizeof(unsigned));
+    cm->total_bytes = (size_t)d.status_off + 256;
+    for (int r = 0; r < COMM_MAX_RANKS; r++) {
+        d.peer[r] = nullptr;
+        cm->opened[r] = false;
+    }
+    hipError_t e = hipGetDevice(&cm->device);
+    void *buf = nullptr;
+    // uncached: peers write it over xGMI behind the local L2's back
+    if (e == hipSuccess) e = hipExtMallocWithFlags(&buf, cm->total_bytes, hipDeviceMallocUncached);
+    if (e == hipSuccess) e = hipMemset(buf, 0, cm->total_bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t *>(handle), buf);
+    if (e != hipSuccess) {
+        if (buf) (void)hipFree(buf);
+        delete cm;
+        return (int)e;
+    }
+    d.peer[rank] = static_cast<char *>(buf);
+    *comm = cm;
+    return 0;
+}
+
+int ccnn_comm_connect(ccnn_comm_t *cm, const void *handles)
+{
+    if (!cm || !handles) return CCNN_E_INVALID;
+    const hipIpcMemHandle_t *h = static_cast<const hipIpcMemHandle_t *>(handles);
+    for (int r = 0; r < cm->dev.world; r++) {
+        if (r == cm->dev.rank || cm->dev.peer[r]) continue;
+        void *p = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&p, h[r], hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return (int)e;
+        cm->dev.peer[r] = static_cast<char *>(p);
+        cm->opened[r] = true;
+    }
+    return 0;
+}
+
+int ccnn_comm_connect_local(ccnn_comm_t *cm, ccnn_comm_t *const *peers)
+{
+    if (!cm || !peers) return CCNN_E_INVALID;
+    for (int r = 0; r < cm->dev.world; r++) {
+        if (r == cm->dev.rank) continue;
+        if (!peers[r] || peers[r]->dev.rank != r || peers[r]->dev.world != cm->dev.world ||
+            peers[r]->total_bytes != cm->total_bytes)
+            return CCNN_E_INVALID;
+        if (peers[r]->device != cm->device) {
+            hipError_t e = hipDeviceEnablePeerAccess(peers[r]->device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return (int)e;
+            (void)hipGetLastError();
+        }
+        cm->dev.peer[r] = peers[r]->dev.peer[r];
+    }
+    return 0;
+}
+
+int ccnn_comm_status(ccnn_comm_t *cm, int *status)
+{
+    if (!cm || !status) return CCNN_E_INVALID;
+    unsigned v = 0;
+    hipError_t e = hipMemcpy(&v, cm->dev.peer[cm->dev.rank] + cm->dev.status_off, sizeof(v), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return (int)e;
+    *status = (int)v;
+    return 0;
+}
+
+int ccnn_comm_destroy(ccnn_comm_t *cm)
+{
+    if (!cm) return 0;
+    for (int r = 0; r < cm->dev.world; r++)
+        if (cm->opened[r]) (void)hipIpcCloseMemHandle(cm->dev.peer[r]);
+    if (cm->dev.peer[cm->dev.rank]) (void)hipFree(cm->dev.peer[cm->dev.rank]);
+    delete cm;
+    return 0;
+}
+
+int ccnn_allreduce_f32(ccnn_comm_t *cm, float *buf, long n, void *stream)
+{
+    return allreduce_launch<float>(cm, buf, buf, n, RulePlain(), stream);
+}
+
+int ccnn_allreduce_f64(ccnn_comm_t *cm, double *buf, long n, void *stream)
+{
+    return allreduce_launch<double>(cm, buf, buf, n, RulePlain(), stream);
+}
+
+int ccnn_allreduce_update_f32(ccnn_comm_t *cm, float *params, const float *grad, float lr, int z,
+                              int freeze_conv_bias, void *stream)
+{
+    ccnn_dims_t d;
+    if (make_dims(z, &d)) return CCNN_E_INVALID;
+    RuleSgd<float> rule{lr, 1.0f, freeze_conv_bias ? (long)d.off_b0 : 0L, freeze_conv_bias ? (long)d.off_w1 : 0L};
+    return allreduce_launch<float>(cm, params, grad, d.nparams, rule, stream);
+}
+
+int ccnn_allreduce_update_f64(ccnn_comm_t *cm, double *params, const double *grad, double lr, int divisor, long n,
+                              void *stream)
+{
+    if (divisor <= 0) return CCNN_E_INVALID;
+    RuleSgd<double> rule{lr, (double)divisor, 0L, 0L};
+    return allreduce_launch<double>(cm, params, grad, n, rule, stream);
+}
+
+}  // extern "C"

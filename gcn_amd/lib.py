@@ -55,6 +55,15 @@ _SIG = {
     "ccnn_host_init_params_f32": (C.c_int, [_P, C.c_int]),
     "ccnn_host_sched_init": (C.c_int, [C.POINTER(LrSched), C.c_double, C.c_int]),
     "ccnn_host_sched_step": (C.c_int, [C.POINTER(LrSched), C.c_double, C.POINTER(C.c_double)]),
+    "ccnn_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_long, C.c_int, C.POINTER(_P), _P]),
+    "ccnn_comm_connect": (C.c_int, [_P, _P]),
+    "ccnn_comm_connect_local": (C.c_int, [_P, C.POINTER(_P)]),
+    "ccnn_comm_status": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "ccnn_comm_destroy": (C.c_int, [_P]),
+    "ccnn_allreduce_f32": (C.c_int, [_P, _P, C.c_long, _P]),
+    "ccnn_allreduce_f64": (C.c_int, [_P, _P, C.c_long, _P]),
+    "ccnn_allreduce_update_f32": (C.c_int, [_P, _P, _P, C.c_float, C.c_int, C.c_int, _P]),
+    "ccnn_allreduce_update_f64": (C.c_int, [_P, _P, _P, C.c_double, C.c_int, C.c_long, _P]),
     "ccnn_profile_enable": (C.c_int, [C.c_int]),
     "ccnn_profile_report": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
     "ccnn_host_partition": (C.c_int, [C.c_long, C.c_int, C.c_int, C.c_int, C.c_long,

@@ -75,7 +75,12 @@ class _Group:
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
 
     def all_reduce(self, t):
-        self.dist.all_reduce(t, group=self.group)
+        if t.is_cuda and self.dist.get_backend(self.group) == "gloo":   # gloo reduces host tensors
+            h = t.cpu()
+            self.dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+        else:
+            self.dist.all_reduce(t, group=self.group)
         return t
 
 
@@ -125,6 +130,18 @@ def fit_mbgd(params, cubes, onehot, z, batch=100, lr=None, min_err=None, max_ite
     if batch_num * sub_b > n_local:
         raise ValueError("this rank's slice is shorter than batch_num sub-batches")
     st = stepper or MbgdStepper(params, cubes, onehot, z)
+    node = None
+    if distributed and stepper is None and params.is_cuda and comm.world > 1:
+        # gradient exchange + update in one kernel over xGMI; the group's own all_reduce (RCCL)
+        # stays the fallback when the exchange cannot be set up or fails its self-test
+        from .comm import NodeComm
+        try:
+            node = NodeComm(params.numel(), params.dtype, group=group)
+            if not node.self_test(rounds=2):
+                node.close()
+                node = None
+        except Exception:   # raised on every rank alike (see NodeComm)
+            node = None
     sched = prep.LrSchedule(fifo_init, use_float=f32)
     loss_d = torch.zeros((max(batch_num, 1), sub_b), dtype=torch.float64, device=params.device)
     hist = History()
@@ -133,6 +150,8 @@ def fit_mbgd(params, cubes, onehot, z, batch=100, lr=None, min_err=None, max_ite
             first = i0 * sub_b
             if comm.world == 1 and stepper is None:
                 st.step_fused(first, sub_b, lr, loss_d[i0])
+            elif node is not None:
+                node.allreduce_update(params, st.grad(first, sub_b, loss_d[i0]), lr, z, divisor=batch)
             else:
                 g = comm.all_reduce(st.grad(first, sub_b, loss_d[i0]))
                 st.update(g, lr, batch)
@@ -161,6 +180,8 @@ def fit_mbgd(params, cubes, onehot, z, batch=100, lr=None, min_err=None, max_ite
         if single_rate < min_err:                             # after the schedule (gcn_mbgd_fp64.cu:1117-1118)
             hist.stopped_early = True
             break
+    if node is not None:
+        node.close()
     return hist
 
 

@@ -220,6 +220,38 @@ int ccnn_host_partition(long n_train, int batch, int n_ranks, int rank, long ste
                         long *first_sample, int *sub_batch);
 
 
+/* ---- multi-GPU exchange ------------------------------------------------------
+ * Replaces the weight broadcast, per-device slab gather and master-side update of
+ * hyper_version_mGPU_MBGD.cu:962-978, 1093-1171 by one kernel per step: every rank
+ * writes its flat gradient straight into the other ranks' exchange buffers over
+ * xGMI, then sums the n contributions in rank order (bit-identical on all ranks)
+ * and applies the update to its own copy of the parameters.
+ *
+ * One ccnn_comm_t per rank and device.  ccnn_comm_create (device = the current one)
+ * allocates the rank's exchange buffer for vectors of up to max_elems elements and
+ * returns its IPC handle (CCNN_COMM_HANDLE_BYTES bytes); the caller passes all
+ * ranks' handles, rank-major, to ccnn_comm_connect (one process per GPU), or the
+ * other ranks' comm objects to ccnn_comm_connect_local (all GPUs in one process).
+ * Collective calls must be issued by all ranks in the same order; on one rank they
+ * are ordered by the stream.  At most 16 ranks.  ccnn_comm_status synchronises and
+ * reports 1 if a rank ever gave up waiting for a peer (peer process gone). */
+#define CCNN_COMM_HANDLE_BYTES 64
+typedef struct ccnn_comm ccnn_comm_t;
+int ccnn_comm_create(int world, int rank, long max_elems, int elem_size, ccnn_comm_t **comm,
+                     void *handle);
+int ccnn_comm_connect(ccnn_comm_t *comm, const void *handles);
+int ccnn_comm_connect_local(ccnn_comm_t *comm, ccnn_comm_t *const *peers);
+int ccnn_comm_status(ccnn_comm_t *comm, int *status);
+int ccnn_comm_destroy(ccnn_comm_t *comm);
+/* buf[k] = sum over ranks of buf[k], in place. */
+int ccnn_allreduce_f32(ccnn_comm_t *comm, float *buf, long n, void *stream);
+int ccnn_allreduce_f64(ccnn_comm_t *comm, double *buf, long n, void *stream);
+/* all-reduce of grad fused with ccnn_update_f32 / ccnn_update_f64 (same arguments). */
+int ccnn_allreduce_update_f32(ccnn_comm_t *comm, float *params, const float *grad, float lr, int z,
+                              int freeze_conv_bias, void *stream);
+int ccnn_allreduce_update_f64(ccnn_comm_t *comm, double *params, const double *grad, double lr,
+                              int divisor, long n, void *stream);
+
 /* Measurement hooks (no counterpart in the reference).  While enabled, every
  * kernel launch of this library carries a start/stop HIP event pair on its own
  * stream (attached to the dispatch, so the interval is the kernel's own).  ccnn_profile_report(i, ...) returns 1 and the i-th kernel's name,

@@ -1,0 +1,108 @@
+"""Worker of tests/test_gpu_comm.py: one rank of a node-local exchange test.  All ranks share
+cuda:0 (the test box has one GPU); the rendezvous and the reference all-reduce use gloo."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from gcn_amd import lib as L  # noqa: E402
+from gcn_amd import ops  # noqa: E402
+from gcn_amd.comm import NodeComm  # noqa: E402
+
+
+def fit(rank, world, dev):
+    """Two epochs of data-parallel fp64 MBGD through the product's driver (HIP gradient kernels,
+    one-shot exchange fused with the update) against the oracle's master/worker replay."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as orc
+    from gcn_amd import train
+    z, T, B, epochs = 48, 64 * world + 5, 8 * world, 2
+    rng = np.random.default_rng(11)
+    cubes = rng.random((T, 9 * z))
+    onehot = np.zeros((T, 13), dtype=np.int32)
+    onehot[np.arange(T), rng.integers(0, 13, T)] = 1
+    orc.srand(11)
+    params = orc.init_params_f64(z, 0)
+    sl = T // world
+    p = torch.from_numpy(params.copy()).to(dev)
+    lc = torch.from_numpy(np.ascontiguousarray(cubes[rank * sl:(rank + 1) * sl])).to(dev)
+    lo = torch.from_numpy(np.ascontiguousarray(onehot[rank * sl:(rank + 1) * sl])).to(dev)
+    hist = train.fit_mbgd(p, lc, lo, z, batch=B, lr=0.5, min_err=0.0, max_iter=epochs, distributed=True, train_size=T)
+    ref, ref_loss = params.copy(), []
+    for _ in range(epochs):
+        tot = 0.0
+        for i0 in range(T // B):
+            tot += orc.mgpu_step_f64(ref, cubes, onehot, T, i0, B, world, z, 0.5)
+        ref_loss.append(tot / T)
+    got = p.cpu().numpy()
+    assert np.abs(got - ref).max() <= 1e-10 * np.abs(ref).max(), np.abs(got - ref).max()
+    assert np.allclose(hist.loss, ref_loss, rtol=1e-10), (hist.loss, ref_loss)
+    every = [torch.empty(p.numel(), dtype=p.dtype) for _ in range(world)]
+    dist.all_gather(every, p.cpu())
+    assert all(torch.equal(every[0], e) for e in every)
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    if "--fit" in sys.argv:
+        fit(rank, world, dev)
+        if rank == 0:
+            print("FIT-OK", world, flush=True)
+        dist.destroy_process_group()
+        return
+    z = 103
+    d = L.dims(z)
+    for dtype in (torch.float32, torch.float64):
+        comm = NodeComm(d.nparams, dtype)
+        print(f"[rank {rank}] {dtype} connected", file=sys.stderr, flush=True)
+        t0 = time.perf_counter()
+        a = torch.ones(8, dtype=dtype, device=dev)
+        comm.all_reduce(a)
+        torch.cuda.synchronize()
+        print(f"[rank {rank}] first all_reduce {time.perf_counter() - t0:.3f}s -> {a[0].item()} status {comm.status()}",
+              file=sys.stderr, flush=True)
+        assert comm.status() == 0, "a rank gave up waiting for its peers"
+        assert comm.self_test(), "one-shot all-reduce disagrees with the group's all_reduce"
+        # short vector (one partial chunk) and repeated calls (slot parity, sequence numbers)
+        for n in (1, 5, 1023, 1025):
+            for k in range(3):
+                a = torch.full((n,), float(rank + 1 + k), dtype=dtype, device=dev)
+                comm.all_reduce(a)
+                torch.cuda.synchronize()
+                want = sum(r + 1 + k for r in range(world))
+                assert bool((a == want).all()), (n, k, a[:4], want)
+        # fused update == all_reduce + stand-alone update, bit for bit
+        g = torch.Generator().manual_seed(7 + rank)
+        grad = (torch.rand(d.nparams, generator=g, dtype=torch.float64) - 0.5).to(dtype).to(dev)
+        p0 = (torch.rand(d.nparams, generator=torch.Generator().manual_seed(3), dtype=torch.float64) - 0.5).to(dtype).to(dev)
+        p_fused, p_ref = p0.clone(), p0.clone()
+        comm.allreduce_update(p_fused, grad, 0.04, z, divisor=100)
+        parts = [torch.empty(d.nparams, dtype=dtype) for _ in range(world)]
+        dist.all_gather(parts, grad.cpu())
+        total = torch.zeros_like(grad)
+        for r in range(world):   # rank order, like the kernel
+            total = total + parts[r].to(dev)
+        ops.update(p_ref, total, 0.04, z, divisor=100)
+        torch.cuda.synchronize()
+        assert torch.equal(p_fused, p_ref), float((p_fused - p_ref).abs().max())
+        # every rank ends with identical parameters
+        every = [torch.empty(d.nparams, dtype=dtype) for _ in range(world)]
+        dist.all_gather(every, p_fused.cpu())
+        assert all(torch.equal(every[0], e) for e in every)
+        assert comm.status() == 0
+        comm.close()
+    if rank == 0:
+        print("COMM-OK", world, flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
