@@ -10,6 +10,7 @@
 // trainer.  Options (all before the positional arguments):
 //   --variant=V  --seed=N (default: time, like the reference)  --epochs=N (300)
 //   --batch=N (100)  --model=PATH (load weights instead of initialising)
+//   --exchange=rccl|oneshot (multi-GPU form: gradient exchange, default rccl)
 //   --infer (skip training; needs --model)
 //   --mat-info=FILE, --mat-rewrite=SRC:DST   MAT-file utilities, no GPU needed
 // stdout keeps the reference's lines and spacing so tools/run.sh's field cuts work.
@@ -57,6 +58,7 @@ struct Options {
     long seed = -1;
     int epochs = 300, batch = 100;
     bool infer = false;
+    std::string exchange = "rccl";   // multi-GPU gradient exchange: rccl | oneshot
     std::vector<std::string> pos;
 };
 
@@ -273,8 +275,25 @@ double run(const Options &opt, const Variant &v, const matio::Array &scene_a, co
         D.ws_bytes = v.sgd ? ccnn_sgd_workspace_bytes(z) : ccnn_mbgd_workspace_bytes(sub_b, z, (int)sizeof(T));
         CK(hipMalloc(&D.ws, D.ws_bytes));
     }
+    // Multi-GPU gradient exchange: RCCL all-reduce + update, or (--exchange=oneshot) the library's
+    // one-kernel exchange over directly mapped peer buffers, fused with the update.
+    const bool oneshot = multi && !v.sgd && opt.exchange == "oneshot";
+    const bool exchange = nd > 1 || oneshot;
     std::vector<ncclComm_t> comms(nd);
-    if (nd > 1) NCK(ncclCommInitAll(comms.data(), nd, devices.data()));
+    std::vector<ccnn_comm_t *> xch(nd, nullptr);
+    if (oneshot) {
+        unsigned char handle[CCNN_COMM_HANDLE_BYTES];
+        for (int k = 0; k < nd; k++) {
+            CK(hipSetDevice(dev[k].id));
+            CK(ccnn_comm_create(nd, k, d.nparams, (int)sizeof(T), &xch[k], handle));
+        }
+        for (int k = 0; k < nd; k++) {
+            CK(hipSetDevice(dev[k].id));
+            CK(ccnn_comm_connect_local(xch[k], xch.data()));
+        }
+    } else if (nd > 1) {
+        NCK(ncclCommInitAll(comms.data(), nd, devices.data()));
+    }
 
     std::vector<double> logloss(300, 0.0);
     char head[96];
@@ -310,7 +329,7 @@ double run(const Options &opt, const Variant &v, const matio::Array &scene_a, co
                         Device<T> &D = dev[k];
                         if (nd > 1) CK(hipSetDevice(D.id));
                         double *lv = D.loss + i0 * sub_b;
-                        if (nd == 1) {
+                        if (!exchange) {
                             if (v.f32)
                                 CK(ccnn_mbgd_step_f32((float *)D.params, (const float *)D.cubes, D.onehot, i0 * sub_b,
                                                       sub_b, z, (float)lr, lv, D.ws, D.ws_bytes, D.st));
@@ -323,7 +342,13 @@ double run(const Options &opt, const Variant &v, const matio::Array &scene_a, co
                                                   D.ws_bytes, D.st));
                         }
                     }
-                    if (nd > 1) {
+                    if (oneshot) {
+                        for (int k = 0; k < nd; k++) {
+                            if (nd > 1) CK(hipSetDevice(dev[k].id));
+                            CK(ccnn_allreduce_update_f64(xch[k], (double *)dev[k].params, (const double *)dev[k].grad, lr,
+                                                         B, d.nparams, dev[k].st));
+                        }
+                    } else if (nd > 1) {
                         // replaces weight broadcast + slab gather + master update
                         // (hyper_version_mGPU_MBGD.cu:962-978, 1093-1171)
                         NCK(ncclGroupStart());
@@ -387,8 +412,16 @@ double run(const Options &opt, const Variant &v, const matio::Array &scene_a, co
     CK(hipMemcpyAsync(&right, count_d, sizeof(int), hipMemcpyDeviceToHost, dev[0].st));
     CK(hipStreamSynchronize(dev[0].st));
     fprintf(stdout, "[Cube CNN testing] Execution time is %.3f sec. ", secs(t_test));
-    if (nd > 1)
+    if (oneshot) {
+        for (int k = 0; k < nd; k++) {
+            CK(hipSetDevice(dev[k].id));
+            CK(hipDeviceSynchronize());
+        }
+        for (auto c : xch) ccnn_comm_destroy(c);
+        CK(hipSetDevice(dev[0].id));
+    } else if (nd > 1) {
         for (auto c : comms) ncclCommDestroy(c);
+    }
     return s.n_test ? (double)right / s.n_test : 0.0;
 }
 
@@ -439,6 +472,7 @@ int main(int argc, char *argv[])
         else if (a.rfind("--seed=", 0) == 0) opt.seed = atol(a.c_str() + 7);
         else if (a.rfind("--epochs=", 0) == 0) opt.epochs = atoi(a.c_str() + 9);
         else if (a.rfind("--batch=", 0) == 0) opt.batch = atoi(a.c_str() + 8);
+        else if (a.rfind("--exchange=", 0) == 0) opt.exchange = a.substr(11);
         else if (a.rfind("--model=", 0) == 0) opt.model = a.substr(8);
         else if (a == "--infer") opt.infer = true;
         else opt.pos.push_back(a);
@@ -477,6 +511,10 @@ int main(int argc, char *argv[])
     }
     if (opt.infer && opt.model.empty()) {
         fprintf(stderr, "--infer needs --model=PATH\n");
+        return 1;
+    }
+    if (opt.exchange != "rccl" && opt.exchange != "oneshot") {
+        fprintf(stderr, "unknown --exchange '%s' (rccl, oneshot)\n", opt.exchange.c_str());
         return 1;
     }
     if (opt.batch <= 0 || opt.epochs < 0) {

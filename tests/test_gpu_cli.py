@@ -116,11 +116,13 @@ def test_sgd_cli_and_inference_mode(tmp_path):
     assert abs(float([l for l in out2.splitlines() if "Accuracy" in l][0].split(" ")[9].rstrip("%")) - acc) < 1e-9
 
 
-def test_multi_gpu_form_with_one_device(tmp_path):
-    """`gcn DATASET.mat device_num master_dev_id` with device_num = 1 is the fp64 minibatch trainer."""
+@pytest.mark.parametrize("extra", [[], ["--exchange=oneshot"]])
+def test_multi_gpu_form_with_one_device(tmp_path, extra):
+    """`gcn DATASET.mat device_num master_dev_id` with device_num = 1 is the fp64 minibatch trainer;
+    --exchange=oneshot sends the step through the gradient / one-kernel exchange + update path."""
     path, scene, labels = make_dataset(tmp_path, np.float64)
     B, epochs = 20, 2
-    out = run_gcn(tmp_path, [f"--seed={SEED}", f"--epochs={epochs}", f"--batch={B}", path, "1", "0"])
+    out = run_gcn(tmp_path, [f"--seed={SEED}", f"--epochs={epochs}", f"--batch={B}", *extra, path, "1", "0"])
     _, l_ref, acc_ref, _ = oracle_run(scene, labels, np.float64, B, 0.5, epochs)
     losses, acc_line, _ = parse(out)
     assert np.allclose(losses, l_ref, rtol=2e-5, atol=1e-6)
