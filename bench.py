@@ -147,10 +147,13 @@ def main():
             # gradient + update fused (nothing has to happen in between on one GPU)
             ops.mbgd_step(params, cubes, onehot_d, b * B, B, z, lr, loss_values=loss_ring[b], workspace=ws)
         else:
-            ops.mbgd_grad(params, cubes, onehot_d, b * B, B, z, grad=grad, loss_values=loss_ring[b], workspace=ws)
             if comm is not None:
-                comm.allreduce_update(params, grad, lr, z)
+                # two launches: the reduction kernel trades its sums with the other ranks and updates
+                ops.mbgd_step(params, cubes, onehot_d, b * B, B, z, lr, loss_values=loss_ring[b], workspace=ws,
+                              comm=comm)
             else:
+                ops.mbgd_grad(params, cubes, onehot_d, b * B, B, z, grad=grad, loss_values=loss_ring[b],
+                              workspace=ws)
                 dist.all_reduce(grad)
                 ops.update(params, grad, lr, z)
 
@@ -297,7 +300,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}-shaped {x}x{y}x{z} fp32 MBGD", "batch_per_gpu": B,
                        "global_batch": B * world, "train_pixels": T, "parallelism": f"dp{world}",
-                       "exchange": ("none" if not use_dist else "xgmi one-shot all-reduce fused with update"
+                       "exchange": ("none" if not use_dist else "xgmi one-shot exchange inside the reduction kernel"
                                     if comm is not None else "rccl all-reduce + update"),
                        "replicas_identical": replicas_identical},
             "infer_pixels_per_s": round(infer_pps, 1),

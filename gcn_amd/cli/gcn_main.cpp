@@ -336,6 +336,12 @@ double run(const Options &opt, const Variant &v, const matio::Array &scene_a, co
                             else
                                 CK(ccnn_mbgd_step_f64((double *)D.params, (const double *)D.cubes, D.onehot, i0 * sub_b,
                                                       sub_b, z, lr, lv, D.ws, D.ws_bytes, D.st));
+                        } else if (oneshot) {
+                            // gradient, exchange with the other devices and update in two launches; the
+                            // launches are asynchronous, so device k's kernel waits for its peers' while
+                            // this loop goes on to start them
+                            CK(ccnn_mbgd_step_dp_f64(xch[k], (double *)D.params, (const double *)D.cubes, D.onehot,
+                                                     i0 * sub_b, sub_b, z, lr, B, lv, D.ws, D.ws_bytes, D.st));
                         } else {
                             CK(ccnn_mbgd_grad_f64((const double *)D.params, (const double *)D.cubes, D.onehot,
                                                   i0 * sub_b, sub_b, z, (double *)D.grad, lv, nullptr, D.ws,
@@ -343,11 +349,7 @@ double run(const Options &opt, const Variant &v, const matio::Array &scene_a, co
                         }
                     }
                     if (oneshot) {
-                        for (int k = 0; k < nd; k++) {
-                            if (nd > 1) CK(hipSetDevice(dev[k].id));
-                            CK(ccnn_allreduce_update_f64(xch[k], (double *)dev[k].params, (const double *)dev[k].grad, lr,
-                                                         B, d.nparams, dev[k].st));
-                        }
+                        // nothing left to do: the step above exchanged and updated
                     } else if (nd > 1) {
                         // replaces weight broadcast + slab gather + master update
                         // (hyper_version_mGPU_MBGD.cu:962-978, 1093-1171)

@@ -8,7 +8,7 @@
 // a workgroup takes a 4 KB chunk of the vector and
 //   1. writes its chunk of the local gradient into slot [rank] of every peer's buffer over
 //      xGMI (all links busy at once, one hop),
-//   2. makes the writes visible (system-scope fence) and raises flag [rank][chunk] at every peer,
+//   2. waits for its writes to complete and raises flag [rank][chunk] at every peer,
 //   3. waits until its own flags [0..n)[chunk] show this call's sequence number,
 //   4. adds the n slots in rank order - the same order on every rank, so all ranks compute
 //      bit-identical sums - and applies the update rule to its chunk of the parameters.
@@ -20,35 +20,8 @@
 #include <cstdlib>
 #include <new>
 
-#include "ccnn_common.h"
+#include "comm.h"
 #include "profile.h"
-
-namespace ccnn {
-
-constexpr int COMM_MAX_RANKS = 16;
-constexpr int COMM_CHUNK_BYTES = 4096;                      // per workgroup: 256 threads x 16 bytes
-constexpr unsigned long long COMM_SPIN_TICKS = 1000000000ull;   // default wait limit: 10 s of the 100 MHz wall clock
-
-struct CommDev {            // passed to the kernel by value
-    char *peer[COMM_MAX_RANKS];   // every rank's exchange buffer as mapped here ([rank] = the local one)
-    int world, rank;
-    long slot_bytes;              // bytes of one [parity][rank] slot
-    long flags_off, status_off;   // byte offsets inside a buffer
-    int nchunks;
-    unsigned long long spin_ticks;   // how long a workgroup waits for a peer before it gives up
-};
-
-}  // namespace ccnn
-
-struct ccnn_comm {
-    ccnn::CommDev dev;
-    int device;
-    long max_elems;
-    int elem;
-    size_t total_bytes;
-    bool opened[ccnn::COMM_MAX_RANKS];
-    unsigned step;
-};
 
 namespace ccnn {
 
@@ -101,52 +74,20 @@ __global__ __launch_bounds__(256) void allreduce_apply(T *target, const T *src, 
     for (int j = 0; j < VW; j++) v[j] = src[min(e0 + j, n - 1)];
     for (int k = 0; k < c.world; k++) {
         const int r = (c.rank + 1 + k) % c.world;   // start at the next rank: spreads the first writes over the links
-        char *slot = c.peer[r] + ((long)par * c.world + c.rank) * c.slot_bytes;
-        *reinterpret_cast<Vec *>(slot + slot_off) = v;
+        comm_store16(comm_slot(c, r, par, c.rank) + slot_off, &v);
     }
-    // 2. publish: every thread's writes are visible system-wide before any flag goes up
-    __threadfence_system();
-    __syncthreads();
-    if (tid < c.world) {
-        unsigned *flag = reinterpret_cast<unsigned *>(c.peer[tid] + c.flags_off) +
-                         ((long)par * c.world + c.rank) * c.nchunks + chunk;
-        __hip_atomic_store(flag, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    // 3. wait for every rank's chunk
-    char *mine = c.peer[c.rank];
-    unsigned *status = reinterpret_cast<unsigned *>(mine + c.status_off);
-    if (tid < c.world) {
-        const unsigned *flag = reinterpret_cast<const unsigned *>(mine + c.flags_off) +
-                               ((long)par * c.world + tid) * c.nchunks + chunk;
-        const u64 t0 = wall_clock64();
-        unsigned spins = 0;
-        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != step) {
-            // all ranks run this kernel for the same call, so the wait ends; the limit bounds the
-            // damage if a peer process died
-            if ((++spins & 1023) == 0 &&
-                (wall_clock64() - t0 > c.spin_ticks ||
-                 __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))) {
-                __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                break;
-            }
-        }
-    }
-    __syncthreads();
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);   // system scope: nothing below is served from a stale cache
+    // 2. publish, 3. wait for every rank's chunk
+    comm_publish(c, par, step, chunk, tid);
+    comm_wait(c, par, step, chunk, tid);
     // 4. sum in rank order, apply
     T sum[VW];
 #pragma unroll
     for (int j = 0; j < VW; j++) sum[j] = 0;
     for (int r = 0; r < c.world; r++) {
-        const u64 *slot = reinterpret_cast<const u64 *>(mine + ((long)par * c.world + r) * c.slot_bytes + slot_off);
-        union {
-            u64 w[2];
-            T t[VW];
-        } u;
-        u.w[0] = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        u.w[1] = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        Vec u;
+        comm_load16(&u, comm_slot(c, c.rank, par, r) + slot_off);
 #pragma unroll
-        for (int j = 0; j < VW; j++) sum[j] = sum[j] + u.t[j];
+        for (int j = 0; j < VW; j++) sum[j] = sum[j] + u[j];
     }
 #pragma unroll
     for (int j = 0; j < VW; j++)
@@ -162,10 +103,9 @@ int allreduce_launch(ccnn_comm *cm, T *target, const T *src, long n, Rule rule, 
         if (!cm->dev.peer[r]) return CCNN_E_INVALID;   // not connected
     constexpr int CH = COMM_CHUNK_BYTES / sizeof(T);
     const int chunks = (int)((n + CH - 1) / CH);
-    cm->step++;
-    if (cm->step == 0) cm->step = 1;   // 0 is the flags' initial value
+    const unsigned step = cm->next_step();
     launch("allreduce_apply", allreduce_apply<T, Rule>, dim3(chunks), dim3(256), 0, (hipStream_t)stream, target, src,
-           n, cm->dev, cm->step, rule);
+           n, cm->dev, step, rule);
     CCNN_LAUNCH_CHECK();
     return 0;
 }
@@ -195,10 +135,14 @@ int ccnn_comm_create(int world, int rank, long max_elems, int elem_size, ccnn_co
         const long v = atol(ms);
         if (v > 0) d.spin_ticks = (unsigned long long)v * 100000ull;
     }
-    d.nchunks = (int)(((size_t)max_elems * elem_size + COMM_CHUNK_BYTES - 1) / COMM_CHUNK_BYTES);
-    d.slot_bytes = (long)d.nchunks * COMM_CHUNK_BYTES;
+    // 2.5 x the vector: the fused minibatch step ships its sums in launch geometry (padded tiles,
+    // a quarter more) as sequence-tagged words (twice the bytes)
+    const size_t cap_bytes = (size_t)max_elems * elem_size * 5 / 2 + 131072;
+    const int nchunks = (int)((cap_bytes + COMM_CHUNK_BYTES - 1) / COMM_CHUNK_BYTES);
+    d.nflags = nchunks > COMM_MIN_FLAGS ? nchunks : COMM_MIN_FLAGS;
+    d.slot_bytes = (long)nchunks * COMM_CHUNK_BYTES;
     d.flags_off = 2L * world * d.slot_bytes;
-    d.status_off = d.flags_off + (long)align_up((size_t)2 * world * d.nchunks * sizeof(unsigned));
+    d.status_off = d.flags_off + (long)align_up((size_t)2 * world * d.nflags * sizeof(unsigned));
     cm->total_bytes = (size_t)d.status_off + 256;
     for (int r = 0; r < COMM_MAX_RANKS; r++) {
         d.peer[r] = nullptr;

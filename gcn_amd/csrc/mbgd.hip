@@ -18,6 +18,7 @@
 // per-sample chain is fused rather than batched layer by layer; FC1 (100 x Pout) is a
 // matrix-vector product per sample here, read through L2.
 #include "ccnn_device.h"
+#include "comm.h"
 #include "profile.h"
 
 #ifndef CCNN_STOP_PHASE
@@ -364,6 +365,7 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
 //     nb_w2 blocks     dW2[o + 13 n] = sum_b a1[b][n] d2[b][o]
 //     2 blocks         db1 = sum_b d1        1 block   db2 = sum_b d2
 constexpr int GR_THREADS = 512;
+constexpr int GR_TILE_VALUES = 7 * 64 * 4;   // values a dW1 workgroup produces (16 x 112 tile)
 
 template <typename T>
 struct UpdateRule {
@@ -407,6 +409,12 @@ __device__ __forceinline__ T colsum8(int B, int rg, int c, T *red, Term term)
     return tot;
 }
 
+// Batch sums of the per-sample factors, one output element per thread (four in the dW1 tiles),
+// then either stored / applied directly (one GPU) or first summed over the ranks: with
+// xc.world > 0 a workgroup writes its outputs into its slot of every peer's exchange buffer,
+// raises its flag there, waits for the same workgroup of every rank and adds the world
+// contributions in rank order before `upd` sees them (comm.h).  No grid-wide barrier: a
+// workgroup only depends on its namesakes on the other ranks.
 template <typename T>
 __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int off_w1, int off_b1,
                                                           int off_w2, int off_b2,
@@ -416,72 +424,137 @@ __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int o
                                                           const T *__restrict__ d2,
                                                           const T *__restrict__ slab, int nb_w1,
                                                           int nb_w0, int nb_w2, T *__restrict__ grad,
-                                                          UpdateRule<T> upd)
+                                                          UpdateRule<T> upd, CommDev xc, unsigned xstep)
 {
     __shared__ T red[8 * 64];
     const int tid = threadIdx.x;
     int blk = blockIdx.x;
+    int ok[4] = {-1, -1, -1, -1};   // parameter index of this thread's outputs (-1: none)
+    T og[4] = {0, 0, 0, 0};         // and their batch sums
     if (blk < nb_w1) {
         const int lane = tid & 63, wave = tid >> 6;
-        if (wave >= 7) return;
-        const int col = lane & 15, kq = lane >> 4;
-        const int p0 = blk * 16, n0 = wave * 16;
-        const bool pv = p0 + col < pout, nv = n0 + col < H;
-        const T *ap = pool + min(p0 + col, pout - 1);   // clamped: loads stay in bounds, masked below
-        const T *bp = d1 + min(n0 + col, H - 1);
-        typename Mma<T>::acc_t acc = {0, 0, 0, 0};
-        const int ks = (B + 3) >> 2;
-        for (int s = 0; s < ks; s += 16) {   // sixteen k-steps of operands in flight
-            T a[16], w[16];
+        if (wave < 7) {
+            const int col = lane & 15, kq = lane >> 4;
+            const int p0 = blk * 16, n0 = wave * 16;
+            const bool pv = p0 + col < pout, nv = n0 + col < H;
+            const T *ap = pool + min(p0 + col, pout - 1);   // clamped: loads stay in bounds, masked below
+            const T *bp = d1 + min(n0 + col, H - 1);
+            typename Mma<T>::acc_t acc = {0, 0, 0, 0};
+            const int ks = (B + 3) >> 2;
+            for (int s = 0; s < ks; s += 16) {   // sixteen k-steps of operands in flight
+                T a[16], w[16];
 #pragma unroll
-            for (int u = 0; u < 16; u++) {
-                const int b = min(4 * (s + u) + kq, B - 1);
-                a[u] = ap[(long)b * pout];
-                w[u] = bp[(long)b * H];
-            }
+                for (int u = 0; u < 16; u++) {
+                    const int b = min(4 * (s + u) + kq, B - 1);
+                    a[u] = ap[(long)b * pout];
+                    w[u] = bp[(long)b * H];
+                }
 #pragma unroll
-            for (int u = 0; u < 16; u++) {
-                const bool bv = 4 * (s + u) + kq < B;
-                acc = Mma<T>::mma((bv && pv) ? a[u] : T(0), (bv && nv) ? w[u] : T(0), acc);
+                for (int u = 0; u < 16; u++) {
+                    const bool bv = 4 * (s + u) + kq < B;
+                    acc = Mma<T>::mma((bv && pv) ? a[u] : T(0), (bv && nv) ? w[u] : T(0), acc);
+                }
             }
-        }
-        if (nv) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int p = p0 + Mma<T>::row(lane, r);
-                if (p < pout) upd.apply(grad, off_w1 + n0 + col + H * p, acc[r]);
+                ok[r] = (nv && p < pout) ? off_w1 + n0 + col + H * p : -1;
+                og[r] = acc[r];
             }
         }
-        return;
+    } else {
+        blk -= nb_w1;
+        const int c = tid & 63, rg = tid >> 6;
+        if (blk < nb_w0) {
+            const int k = min(blk * 64 + c, F * K + F - 1);
+            const T tot = colsum8<T>(B, rg, c, red, [&](int b) { return slab[(long)b * (F * K + F) + k]; });
+            if (rg == 0 && blk * 64 + c < F * K + F) {   // slab layout = W0 | b0 = params[0..)
+                ok[0] = k;
+                og[0] = tot;
+            }
+        } else if (blk < nb_w0 + nb_w2) {
+            const int k = min((blk - nb_w0) * 64 + c, H * O - 1);   // k = o + 13 n
+            const int nn = k / O, o = k - nn * O;
+            const T tot = colsum8<T>(B, rg, c, red, [&](int b) { return a1[(long)b * H + nn] * d2[(long)b * O + o]; });
+            if (rg == 0 && (blk - nb_w0) * 64 + c < H * O) {
+                ok[0] = off_w2 + k;
+                og[0] = tot;
+            }
+        } else if (blk < nb_w0 + nb_w2 + 2) {
+            const int q = blk - nb_w0 - nb_w2;
+            const int n = min(q * 64 + c, H - 1);
+            const T tot = colsum8<T>(B, rg, c, red, [&](int b) { return d1[(long)b * H + n]; });
+            if (rg == 0 && q * 64 + c < H) {
+                ok[0] = off_b1 + n;
+                og[0] = tot;
+            }
+        } else {
+            const int o = min(c, O - 1);
+            const T tot = colsum8<T>(B, rg, c, red, [&](int b) { return d2[(long)b * O + o]; });
+            if (rg == 0 && c < O) {
+                ok[0] = off_b2 + o;
+                og[0] = tot;
+            }
+        }
     }
-    blk -= nb_w1;
-    const int c = tid & 63, rg = tid >> 6;
-    if (blk < nb_w0) {
-        const int k = min(blk * 64 + c, F * K + F - 1);
-        const T tot = colsum8<T>(B, rg, c, red, [&](int b) { return slab[(long)b * (F * K + F) + k]; });
-        if (rg == 0 && blk * 64 + c < F * K + F) upd.apply(grad, k, tot);   // slab layout = W0 | b0 = params[0..)
-        return;
+    if (xc.world > 0) {
+        // The outputs travel in launch geometry, not in parameter order (a dW1 workgroup's slot
+        // region holds four values per thread, the others one value per lane of their first wave),
+        // each 32-bit half of a value in its own sequence-tagged word (comm.h): a thread trades
+        // with its namesakes on the other ranks without any fence, flag or barrier.  (A
+        // system-scope fence here would have to write back the megabytes of dirty L2 lines the
+        // per-sample kernel has just left behind: measured +14 us per step.)
+        constexpr int WPV = sizeof(T) / 4;   // tagged words per value
+        const int par = xstep & 1;
+        const bool tile = (int)blockIdx.x < nb_w1;
+        const bool sender = tile ? tid < 7 * 64 : tid < 64;
+        const int nv = tile ? 4 : 1;         // values this thread trades
+        const long word0 = (tile ? (long)blockIdx.x * GR_TILE_VALUES + 4 * tid
+                                 : (long)nb_w1 * GR_TILE_VALUES + (long)(blockIdx.x - nb_w1) * 64 + tid) * WPV;
+        if (sender) {
+            unsigned bits[4 * WPV];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (WPV == 1) {
+                    bits[j] = __float_as_uint((float)og[j]);
+                } else {
+                    const unsigned long long q = (unsigned long long)__double_as_longlong((double)og[j]);
+                    bits[2 * j] = (unsigned)q;
+                    bits[2 * j + 1] = (unsigned)(q >> 32);
+                }
+            }
+            for (int k = 0; k < xc.world; k++) {
+                const int r = (xc.rank + 1 + k) % xc.world;   // start at the next rank: spreads the writes over the links
+                unsigned long long *dst = reinterpret_cast<unsigned long long *>(comm_slot(xc, r, par, xc.rank)) + word0;
+#pragma unroll
+                for (int h = 0; h < WPV; h++) comm_store_tagged(dst + 4 * h, bits + 4 * h, max(min(nv * WPV - 4 * h, 4), 0), xstep);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) og[j] = 0;
+            for (int r = 0; r < xc.world; r++) {   // rank order: the same bits on every rank
+                const unsigned long long *src =
+                    reinterpret_cast<const unsigned long long *>(comm_slot(xc, xc.rank, par, r)) + word0;
+                unsigned in[4 * WPV];
+#pragma unroll
+                for (int h = 0; h < WPV; h++)
+                    comm_load_tagged(src + 4 * h, in + 4 * h, max(min(nv * WPV - 4 * h, 4), 0), xstep, xc);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (j < nv) {
+                        if (WPV == 1) {
+                            og[j] = og[j] + (T)__uint_as_float(in[j]);
+                        } else {
+                            const unsigned long long q = (unsigned long long)in[2 * j] | ((unsigned long long)in[2 * j + 1] << 32);
+                            og[j] = og[j] + (T)__longlong_as_double((long long)q);
+                        }
+                    }
+                }
+            }
+        }
     }
-    blk -= nb_w0;
-    if (blk < nb_w2) {
-        const int k = min(blk * 64 + c, H * O - 1);   // k = o + 13 n
-        const int nn = k / O, o = k - nn * O;
-        const T tot = colsum8<T>(B, rg, c, red, [&](int b) { return a1[(long)b * H + nn] * d2[(long)b * O + o]; });
-        if (rg == 0 && blk * 64 + c < H * O) upd.apply(grad, off_w2 + k, tot);
-        return;
-    }
-    blk -= nb_w2;
-    if (blk < 2) {
-        const int n = min(blk * 64 + c, H - 1);
-        const T tot = colsum8<T>(B, rg, c, red, [&](int b) { return d1[(long)b * H + n]; });
-        if (rg == 0 && blk * 64 + c < H) upd.apply(grad, off_b1 + n, tot);
-        return;
-    }
-    {
-        const int o = min(c, O - 1);
-        const T tot = colsum8<T>(B, rg, c, red, [&](int b) { return d2[(long)b * O + o]; });
-        if (rg == 0 && c < O) upd.apply(grad, off_b2 + o, tot);
-    }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (ok[j] >= 0) upd.apply(grad, ok[j], og[j]);
 }
 
 // ---------------------------------------------------------------------------
@@ -513,7 +586,7 @@ struct MbgdWs {
 template <typename T, bool FLIP>
 int mbgd_impl(const T *params, const T *cubes, const int *onehot, long first, int B, int z, T *grad,
               UpdateRule<T> upd, double *loss_values, T *probs, void *ws, size_t ws_bytes,
-              hipStream_t st)
+              hipStream_t st, ccnn_comm *cm = nullptr)
 {
     ccnn_dims_t d;
     if (make_dims(z, &d)) return CCNN_E_INVALID;
@@ -531,10 +604,22 @@ int mbgd_impl(const T *params, const T *cubes, const int *onehot, long first, in
     const int nb_w1 = (d.pout + 15) / 16;
     const int nb_w0 = (F * K + F + 63) / 64;
     const int nb_w2 = (H * O + 63) / 64;
+    const int nblocks = nb_w1 + nb_w0 + nb_w2 + 3;
+    CommDev xc = {};
+    unsigned xstep = 0;
+    if (cm) {
+        // exchange layout: one 8-byte tagged word per 32 payload bits
+        const long xvalues = (long)nb_w1 * GR_TILE_VALUES + (long)(nblocks - nb_w1) * 64;
+        if ((int)sizeof(T) != cm->elem || xvalues * 2 * (long)sizeof(T) > cm->dev.slot_bytes || nblocks > cm->dev.nflags)
+            return CCNN_E_RANGE;
+        for (int r = 0; r < cm->dev.world; r++)
+            if (!cm->dev.peer[r]) return CCNN_E_INVALID;   // not connected
+        xc = cm->dev;
+        xstep = cm->next_step();
+    }
     {
-        launch("grad_reduce", grad_reduce<T>, dim3(nb_w1 + nb_w0 + nb_w2 + 3), dim3(GR_THREADS), 0, st, B, d.pout,
-               d.off_w1, d.off_b1, d.off_w2, d.off_b2, w.pool, w.a1, w.d1, w.d2, w.slab, nb_w1, nb_w0, nb_w2, grad,
-               upd);
+        launch("grad_reduce", grad_reduce<T>, dim3(nblocks), dim3(GR_THREADS), 0, st, B, d.pout, d.off_w1, d.off_b1,
+               d.off_w2, d.off_b2, w.pool, w.a1, w.d1, w.d2, w.slab, nb_w1, nb_w0, nb_w2, grad, upd, xc, xstep);
     }
     CCNN_LAUNCH_CHECK();
     return 0;
@@ -590,6 +675,28 @@ int ccnn_mbgd_step_f64(double *params, const double *cubes, const int *onehot, l
     UpdateRule<double> upd{params, lr, B, 0, 0};   // mean over the batch (gcn_mbgd_fp64.cu:519)
     return mbgd_impl<double, false>(params, cubes, onehot, first, B, z, nullptr, upd, loss_values, nullptr,
                                     workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int ccnn_mbgd_step_dp_f32(ccnn_comm_t *comm, float *params, const float *cubes, const int *onehot, long first,
+                          int B, int z, float lr, double *loss_values, void *workspace, size_t workspace_bytes,
+                          void *stream)
+{
+    ccnn_dims_t d;
+    if (make_dims(z, &d) || !params || !comm) return CCNN_E_INVALID;
+    UpdateRule<float> upd{params, lr, 0, d.off_b0, d.off_w1};
+    return mbgd_impl<float, true>(params, cubes, onehot, first, B, z, nullptr, upd, loss_values, nullptr,
+                                  workspace, workspace_bytes, (hipStream_t)stream, comm);
+}
+
+int ccnn_mbgd_step_dp_f64(ccnn_comm_t *comm, double *params, const double *cubes, const int *onehot, long first,
+                          int B, int z, double lr, int divisor, double *loss_values, void *workspace,
+                          size_t workspace_bytes, void *stream)
+{
+    ccnn_dims_t d;
+    if (make_dims(z, &d) || !params || !comm || divisor <= 0) return CCNN_E_INVALID;
+    UpdateRule<double> upd{params, lr, divisor, 0, 0};   // mean over the GLOBAL batch (hyper_version_mGPU_MBGD.cu:518, 550)
+    return mbgd_impl<double, false>(params, cubes, onehot, first, B, z, nullptr, upd, loss_values, nullptr,
+                                    workspace, workspace_bytes, (hipStream_t)stream, comm);
 }
 
 }  // extern "C"

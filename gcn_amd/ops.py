@@ -154,8 +154,11 @@ def mbgd_grad(params, cubes, onehot, first, B, z, grad=None, loss_values=None, p
     return grad, loss_values
 
 
-def mbgd_step(params, cubes, onehot, first, B, z, lr, loss_values=None, workspace=None):
-    """Gradient and the variant's own update in one call (single GPU); params updated in place."""
+def mbgd_step(params, cubes, onehot, first, B, z, lr, loss_values=None, workspace=None, comm=None, divisor=None):
+    """Gradient and the variant's own update in one call; params updated in place.
+    comm (a gcn_amd.comm.NodeComm): the data-parallel step - this rank's B samples, the sums
+    exchanged with the other ranks inside the reduction kernel; fp64 then divides by `divisor`
+    (the global batch)."""
     sfx, es = _sfx(params.dtype)
     d = _l.dims(z)
     _req(params, params.dtype, "params", d.nparams)
@@ -171,6 +174,12 @@ def mbgd_step(params, cubes, onehot, first, B, z, lr, loss_values=None, workspac
         raise ValueError("loss_values shorter than the batch")
     lib = _l.load()
     ws = (workspace or Workspace(params.device)).get(lib.ccnn_mbgd_workspace_bytes(B, z, es))
+    if comm is not None:
+        fn = getattr(lib, f"ccnn_mbgd_step_dp_{sfx}")
+        extra = () if params.dtype == torch.float32 else (int(divisor if divisor else B * comm.world),)
+        _l.check(fn(comm._h, _ptr(params), _ptr(cubes), _ptr(onehot), first, B, z, float(lr), *extra,
+                    _ptr(loss_values), _ptr(ws), ws.numel(), _stream()), f"ccnn_mbgd_step_dp_{sfx}")
+        return loss_values
     fn = getattr(lib, f"ccnn_mbgd_step_{sfx}")
     _l.check(fn(_ptr(params), _ptr(cubes), _ptr(onehot), first, B, z, float(lr), _ptr(loss_values), _ptr(ws),
                 ws.numel(), _stream()), f"ccnn_mbgd_step_{sfx}")

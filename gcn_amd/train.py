@@ -151,7 +151,8 @@ def fit_mbgd(params, cubes, onehot, z, batch=100, lr=None, min_err=None, max_ite
             if comm.world == 1 and stepper is None:
                 st.step_fused(first, sub_b, lr, loss_d[i0])
             elif node is not None:
-                node.allreduce_update(params, st.grad(first, sub_b, loss_d[i0]), lr, z, divisor=batch)
+                ops.mbgd_step(params, cubes, onehot, first, sub_b, z, lr, loss_values=loss_d[i0], workspace=st.ws,
+                              comm=node, divisor=batch)
             else:
                 g = comm.all_reduce(st.grad(first, sub_b, loss_d[i0]))
                 st.update(g, lr, batch)

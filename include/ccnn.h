@@ -251,6 +251,17 @@ int ccnn_allreduce_update_f32(ccnn_comm_t *comm, float *params, const float *gra
                               int freeze_conv_bias, void *stream);
 int ccnn_allreduce_update_f64(ccnn_comm_t *comm, double *params, const double *grad, double lr,
                               int divisor, long n, void *stream);
+/* The whole data-parallel minibatch step in two launches: ccnn_mbgd_step_* on this rank's B
+ * samples with the exchange inside the batch-reduction kernel (each of its workgroups trades
+ * its outputs with the same workgroup on the other ranks), so no gradient vector is stored and
+ * no third kernel runs.  _f64 divides by `divisor` = the GLOBAL batch
+ * (hyper_version_mGPU_MBGD.cu:518, 550); _f32 applies the plain sum with the conv bias frozen. */
+int ccnn_mbgd_step_dp_f32(ccnn_comm_t *comm, float *params, const float *cubes, const int *onehot,
+                          long first, int B, int z, float lr, double *loss_values, void *workspace,
+                          size_t workspace_bytes, void *stream);
+int ccnn_mbgd_step_dp_f64(ccnn_comm_t *comm, double *params, const double *cubes, const int *onehot,
+                          long first, int B, int z, double lr, int divisor, double *loss_values,
+                          void *workspace, size_t workspace_bytes, void *stream);
 
 /* Measurement hooks (no counterpart in the reference).  While enabled, every
  * kernel launch of this library carries a start/stop HIP event pair on its own

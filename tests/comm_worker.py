@@ -93,6 +93,25 @@ def main():
         ops.update(p_ref, total, 0.04, z, divisor=100)
         torch.cuda.synchronize()
         assert torch.equal(p_fused, p_ref), float((p_fused - p_ref).abs().max())
+        # the step with the exchange inside its reduction kernel == gradient, exchange, update
+        rng = np.random.default_rng(5 + rank)
+        B = 12
+        cubes = torch.from_numpy(rng.random((B, 9 * z))).to(dtype).to(dev)
+        oh = np.zeros((B, 13), dtype=np.int32)
+        oh[np.arange(B), rng.integers(0, 13, B)] = 1
+        oh = torch.from_numpy(oh).to(dev)
+        q_fused, q_ref = p0.clone(), p0.clone()
+        lv1 = ops.mbgd_step(q_fused, cubes, oh, 0, B, z, 0.04, comm=comm, divisor=B * world)
+        g_loc, lv2 = ops.mbgd_grad(q_ref, cubes, oh, 0, B, z)
+        comm.allreduce_update(q_ref, g_loc, 0.04, z, divisor=B * world)
+        torch.cuda.synchronize()
+        assert torch.equal(lv1, lv2)
+        # same sums in the same order; the two kernels may contract p - lr*g differently (1 ulp)
+        tol = 2e-7 if dtype == torch.float32 else 4e-16
+        assert float((q_fused - q_ref).abs().max()) <= tol * float(q_ref.abs().max()), float((q_fused - q_ref).abs().max())
+        every = [torch.empty(d.nparams, dtype=dtype) for _ in range(world)]
+        dist.all_gather(every, q_fused.cpu())
+        assert all(torch.equal(every[0], e) for e in every)
         # every rank ends with identical parameters
         every = [torch.empty(d.nparams, dtype=dtype) for _ in range(world)]
         dist.all_gather(every, p_fused.cpu())
