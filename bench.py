@@ -201,6 +201,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dti = t.item()
     infer_pps = world * te_n * reps / dti
+    # the same pixels classified straight from the scene (no cubes in memory)
+    te_idx_d = torch.from_numpy(np.ascontiguousarray(te9[te_lo:te_lo + te_n])).to(dev)
+    ops.forward_scene(params, scene_d, te_idx_d, x, y, z, want_probs=False, workspace=fws)
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        ops.forward_scene(params, scene_d, te_idx_d, x, y, z, want_probs=False, workspace=fws)
+    fence()
+    dts = time.perf_counter() - t1
+    if world > 1:
+        t = torch.tensor([dts], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dts = t.item()
+    infer_scene_pps = world * te_n * reps / dts
 
     # ---- fp64 per-sample SGD on the same cubes (sequential by definition: replicas only, rank 0 reports)
     sgd_pps = None
@@ -304,6 +318,7 @@ def main():
                                     if comm is not None else "rccl all-reduce + update"),
                        "replicas_identical": replicas_identical},
             "infer_pixels_per_s": round(infer_pps, 1),
+            "infer_from_scene_pixels_per_s": round(infer_scene_pps, 1),
             "sgd_fp64_pixels_per_s": round(sgd_pps, 1),
             "roofline": roof,
             "cpu_baseline": cpu,

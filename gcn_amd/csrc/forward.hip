@@ -44,13 +44,21 @@ constexpr int CONV_MAXREG = 32;   // cube elements a thread may hold in flight f
 // NREG (8, 16, 24 or 32) >= ceil(SPI*cube_len/256) is a template parameter so that the
 // prefetch is straight-line code: loads under a run-time guard are waited for at the
 // guard's join, which would put the whole memory latency back in front of the MFMAs.
-template <typename T, bool FLIP, int SPI, int NREG>
+//
+// SCENE: the samples are not pre-gathered cubes but pixels of the scene: `cubes` is the scene
+// [z][plane], idx9 the neighbour lists, and element b*9+j of a sample's cube is read straight
+// from scene[idx9[sample][j] + b*plane] (preprocessing, gcn_mbgd_fp64.cu:599-615, folded into
+// the load), so full-scene inference never materialises 9z values per pixel in HBM.  The
+// neighbour lists of a group sit in LDS one iteration ahead of the loads that use them.
+template <typename T, bool FLIP, int SPI, int NREG, bool SCENE>
 __global__ __launch_bounds__(256) void conv_pool_fwd(const T *__restrict__ params,
                                                      const T *__restrict__ cubes, long first, int nrows,
                                                      int cube_len, int re, int mre, int off_b0,
-                                                     T *__restrict__ pool)
+                                                     T *__restrict__ pool, const int *__restrict__ idx9,
+                                                     long plane)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int sidx[2][SPI * NB];   // SCENE: neighbour lists of the group being loaded / the one after
     constexpr int RPS = NREG / SPI;                 // prefetch registers per sample
     const int cube_pad = conv_cube_pad(re);
     T *cube = reinterpret_cast<T *>(smem);          // [SPI][cube_pad]
@@ -67,14 +75,30 @@ __global__ __launch_bounds__(256) void conv_pool_fwd(const T *__restrict__ param
     const T bias1 = params[off_b0 + min(16 + col, F - 1)];
 
     T creg[NREG];
-    auto issue = [&](long g) {   // next group's cubes -> registers (clamped, unconditional)
+    auto issue = [&](long g, int ib) {   // next group's cubes -> registers (clamped, unconditional)
 #pragma unroll
         for (int si = 0; si < SPI; si++) {
-            const long r = g * SPI + si < nrows ? g * SPI + si : (long)nrows - 1;
-            const T *src = cubes + (first + r) * (long)cube_len;
+            if (SCENE) {
 #pragma unroll
-            for (int u = 0; u < RPS; u++) creg[si * RPS + u] = src[min(u * 256 + tid, cube_len - 1)];
+                for (int u = 0; u < RPS; u++) {
+                    const int e = min(u * 256 + tid, cube_len - 1);
+                    const int b = e / NB, j = e - b * NB;
+                    creg[si * RPS + u] = cubes[sidx[ib][si * NB + j] + b * plane];
+                }
+            } else {
+                const long r = g * SPI + si < nrows ? g * SPI + si : (long)nrows - 1;
+                const T *src = cubes + (first + r) * (long)cube_len;
+#pragma unroll
+                for (int u = 0; u < RPS; u++) creg[si * RPS + u] = src[min(u * 256 + tid, cube_len - 1)];
+            }
         }
+    };
+    auto load_idx = [&](long g) {   // one neighbour index of group g per thread (clamped, unconditional)
+        const int e = min(tid, SPI * NB - 1);
+        const int si = e / NB, j = e - si * NB;
+        const long gc = g < ngroups ? g : ngroups - 1;
+        const long r = gc * SPI + si < nrows ? gc * SPI + si : (long)nrows - 1;
+        return idx9[(first + r) * NB + j];
     };
     auto commit = [&]() {
 #pragma unroll
@@ -87,16 +111,33 @@ __global__ __launch_bounds__(256) void conv_pool_fwd(const T *__restrict__ param
     };
 
     long g = blockIdx.x;
-    if (g < ngroups) issue(g);
+    int ib = 0;   // sidx[ib] = lists of the group whose loads are issued next
+    if (SCENE) {
+        if (g >= ngroups) return;
+        const int i0 = load_idx(g), i1 = load_idx(g + gridDim.x);
+        if (tid < SPI * NB) {
+            sidx[0][tid] = i0;
+            sidx[1][tid] = i1;
+        }
+        __syncthreads();
+    }
+    if (g < ngroups) issue(g, 0);
+    ib = 1;
     __syncthreads();
     if (g < ngroups) commit();
     for (; g < ngroups; g += gridDim.x) {
         __syncthreads();                                   // this group's cubes are in LDS; pl is free
         const long gn = g + gridDim.x;
-        if (gn < ngroups) issue(gn);                       // next group's loads fly during the MFMAs
+        if (gn < ngroups) issue(gn, ib);                   // next group's loads fly during the MFMAs
+        int inext = 0;
+        if (SCENE) inext = load_idx(gn + gridDim.x);       // and the lists of the group after it
         conv_pool_tiles<T>(cube, cube_pad, SPI, wl, re, bias0, bias1, lane, wave,
                            [&](int si, int f, int m, T v, int) { pl[si * pout + f * mre + m] = v; });
         __syncthreads();                                   // pooled values complete, cubes no longer read
+        if (SCENE) {
+            ib ^= 1;                                       // the lists issue(g) used are dead: reuse their buffer
+            if (tid < SPI * NB) sidx[ib][tid] = inext;
+        }
         if (gn < ngroups) commit();
         const int ns = (int)(((long)nrows - g * SPI) < SPI ? ((long)nrows - g * SPI) : SPI);
         T *dst = pool + (g * SPI) * pout;
@@ -346,9 +387,11 @@ struct FwdWs {
     }
 };
 
+// idx9 == null: `cubes` holds n pre-gathered cubes.  idx9 != null: `cubes` is the scene
+// [z][plane] and sample i is the pixel neighbourhood idx9[i][0..9).
 template <typename T, bool FLIP>
 int forward_impl(const T *params, const T *cubes, long n, int z, T *probs, int *argmax, void *ws,
-                 size_t ws_bytes, hipStream_t st)
+                 size_t ws_bytes, hipStream_t st, const int *idx9 = nullptr, long plane = 0)
 {
     ccnn_dims_t d;
     if (make_dims(z, &d)) return CCNN_E_INVALID;
@@ -361,13 +404,17 @@ int forward_impl(const T *params, const T *cubes, long n, int z, T *probs, int *
     const int nreg8 = (spi * ((d.cube + 255) / 256) + 7) / 8;   // prefetch registers per thread, in eights
     if (nreg8 > CONV_MAXREG / 8) return CCNN_E_RANGE;
     const size_t csm = conv_smem<T>(d, spi);
-    typedef void (*ConvKern)(const T *, const T *, long, int, int, int, int, int, T *);
-    static const ConvKern kern[2][4] = {
-        {conv_pool_fwd<T, FLIP, 2, 8>, conv_pool_fwd<T, FLIP, 2, 16>, conv_pool_fwd<T, FLIP, 2, 24>,
-         conv_pool_fwd<T, FLIP, 2, 32>},
-        {conv_pool_fwd<T, FLIP, 4, 8>, conv_pool_fwd<T, FLIP, 4, 16>, conv_pool_fwd<T, FLIP, 4, 24>,
-         conv_pool_fwd<T, FLIP, 4, 32>}};
-    const ConvKern conv = kern[spi == 4][nreg8 - 1];
+    typedef void (*ConvKern)(const T *, const T *, long, int, int, int, int, int, T *, const int *, long);
+    static const ConvKern kern[2][2][4] = {
+        {{conv_pool_fwd<T, FLIP, 2, 8, false>, conv_pool_fwd<T, FLIP, 2, 16, false>,
+          conv_pool_fwd<T, FLIP, 2, 24, false>, conv_pool_fwd<T, FLIP, 2, 32, false>},
+         {conv_pool_fwd<T, FLIP, 4, 8, false>, conv_pool_fwd<T, FLIP, 4, 16, false>,
+          conv_pool_fwd<T, FLIP, 4, 24, false>, conv_pool_fwd<T, FLIP, 4, 32, false>}},
+        {{conv_pool_fwd<T, FLIP, 2, 8, true>, conv_pool_fwd<T, FLIP, 2, 16, true>,
+          conv_pool_fwd<T, FLIP, 2, 24, true>, conv_pool_fwd<T, FLIP, 2, 32, true>},
+         {conv_pool_fwd<T, FLIP, 4, 8, true>, conv_pool_fwd<T, FLIP, 4, 16, true>,
+          conv_pool_fwd<T, FLIP, 4, 24, true>, conv_pool_fwd<T, FLIP, 4, 32, true>}}};
+    const ConvKern conv = kern[idx9 != nullptr][spi == 4][nreg8 - 1];
     if (int e = allow_smem(conv, csm)) return e;
     if (int e = allow_smem(fc_head_fwd<T>, FcHeadLds<T>::bytes)) return e;
     for (long s0 = 0; s0 < n; s0 += rows) {
@@ -376,7 +423,7 @@ int forward_impl(const T *params, const T *cubes, long n, int z, T *probs, int *
         const int pg = groups < PERSIST_GRID ? groups : PERSIST_GRID;
         {
             launch("conv_pool_fwd", conv, dim3(pg), dim3(256), csm, st, params, cubes, s0, nr, d.cube, d.re, d.mre,
-                   d.off_b0, w.pool);
+                   d.off_b0, w.pool, idx9, plane);
         }
         CCNN_LAUNCH_CHECK();
         {
@@ -415,6 +462,25 @@ int ccnn_forward_f64(const double *params, const double *cubes, long n, int z, d
 {
     return forward_impl<double, false>(params, cubes, n, z, probs, argmax, workspace, workspace_bytes,
                                        (hipStream_t)stream);
+}
+
+int ccnn_forward_scene_f32(const float *params, const float *scene, const int *idx9, long n, int x, int y, int z,
+                           float *probs, int *argmax, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!idx9 && n > 0) return CCNN_E_INVALID;
+    if (x <= 0 || y <= 0 || (long)x * y > 0x7fffffffL) return CCNN_E_RANGE;
+    return forward_impl<float, true>(params, scene, n, z, probs, argmax, workspace, workspace_bytes,
+                                     (hipStream_t)stream, idx9, (long)x * y);
+}
+
+int ccnn_forward_scene_f64(const double *params, const double *scene, const int *idx9, long n, int x, int y,
+                           int z, double *probs, int *argmax, void *workspace, size_t workspace_bytes,
+                           void *stream)
+{
+    if (!idx9 && n > 0) return CCNN_E_INVALID;
+    if (x <= 0 || y <= 0 || (long)x * y > 0x7fffffffL) return CCNN_E_RANGE;
+    return forward_impl<double, false>(params, scene, n, z, probs, argmax, workspace, workspace_bytes,
+                                       (hipStream_t)stream, idx9, (long)x * y);
 }
 
 int ccnn_count_correct(const int *argmax, const int *labels, long n, int *count, void *stream)

@@ -67,6 +67,8 @@ _SIG = {
     "ccnn_mbgd_step_dp_f32": (C.c_int, [_P, _P, _P, _P, C.c_long, C.c_int, C.c_int, C.c_float, _P, _P, C.c_size_t, _P]),
     "ccnn_mbgd_step_dp_f64": (C.c_int, [_P, _P, _P, _P, C.c_long, C.c_int, C.c_int, C.c_double, C.c_int, _P, _P,
                                         C.c_size_t, _P]),
+    "ccnn_forward_scene_f32": (C.c_int, [_P, _P, _P, C.c_long, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_size_t, _P]),
+    "ccnn_forward_scene_f64": (C.c_int, [_P, _P, _P, C.c_long, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_size_t, _P]),
     "ccnn_profile_enable": (C.c_int, [C.c_int]),
     "ccnn_profile_report": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
     "ccnn_host_partition": (C.c_int, [C.c_long, C.c_int, C.c_int, C.c_int, C.c_long,

@@ -99,6 +99,28 @@ def forward(params, cubes, z, want_probs=True, want_argmax=True, workspace=None)
     return probs, argmax
 
 
+def forward_scene(params, scene, idx9, x, y, z, want_probs=True, want_argmax=True, workspace=None):
+    """forward() on pixels of the scene: idx9 int32 [n, 9] neighbour lists; no cubes are stored."""
+    sfx, es = _sfx(params.dtype)
+    d = _l.dims(z)
+    _req(params, params.dtype, "params", d.nparams)
+    _req(scene, params.dtype, "scene", x * y * z)
+    _req(idx9, torch.int32, "idx9")
+    n = idx9.numel() // 9
+    if idx9.numel() != n * 9:
+        raise ValueError("idx9 must hold 9 indices per sample")
+    probs = torch.empty((n, 13), dtype=params.dtype, device=params.device) if want_probs else None
+    argmax = torch.empty(n, dtype=torch.int32, device=params.device) if want_argmax else None
+    if n == 0:
+        return probs, argmax
+    lib = _l.load()
+    ws = (workspace or Workspace(params.device)).get(lib.ccnn_forward_workspace_bytes(n, z, es))
+    fn = getattr(lib, f"ccnn_forward_scene_{sfx}")
+    _l.check(fn(_ptr(params), _ptr(scene), _ptr(idx9), n, x, y, z, _ptr(probs), _ptr(argmax), _ptr(ws), ws.numel(),
+                _stream()), f"ccnn_forward_scene_{sfx}")
+    return probs, argmax
+
+
 def count_correct(argmax, labels):
     """Device count of argmax+1 == labels; returns a 1-element int32 tensor."""
     _req(argmax, torch.int32, "argmax")

@@ -94,6 +94,19 @@ int ccnn_forward_f32(const float *params, const float *cubes, long n, int z, flo
 int ccnn_forward_f64(const double *params, const double *cubes, long n, int z, double *probs,
                      int *argmax, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ccnn_forward_* fed from the scene instead of pre-gathered cubes: sample i is the
+ * neighbourhood idx9[i][0..9) and its cube element b*9+j is read as
+ * scene[idx9[i][j] + b*x*y] inside the convolution kernel (preprocessing,
+ * gcn_mbgd_fp64.cu:599-615, folded into the test loop :1160-1209), so full-scene
+ * inference never writes 9z values per pixel to memory.  Results are identical to
+ * ccnn_gather_* followed by ccnn_forward_*.  Same workspace as ccnn_forward_*. */
+int ccnn_forward_scene_f32(const float *params, const float *scene, const int *idx9, long n, int x,
+                           int y, int z, float *probs, int *argmax, void *workspace,
+                           size_t workspace_bytes, void *stream);
+int ccnn_forward_scene_f64(const double *params, const double *scene, const int *idx9, long n, int x,
+                           int y, int z, double *probs, int *argmax, void *workspace,
+                           size_t workspace_bytes, void *stream);
+
 /* Number of i < n with argmax[i] + 1 == labels[i], written to *count (device int).
  * Replaces the per-pixel D2H + count_err accumulation (gcn_mbgd_fp64.cu:1226-1230). */
 int ccnn_count_correct(const int *argmax, const int *labels, long n, int *count, void *stream);

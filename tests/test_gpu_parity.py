@@ -96,6 +96,30 @@ def test_forward_ksc_checkpoint(golden):
     assert np.array_equal(am.cpu().numpy(), g["argmax"])
 
 
+@pytest.mark.parametrize("dtype,z", [(np.float32, 103), (np.float64, 60), (np.float32, 224), (np.float64, 176)])
+def test_forward_scene_equals_gather_then_forward(dtype, z):
+    """The scene-fed forward (neighbourhoods read inside the conv kernel) is bit-identical to
+    gathering cubes first, on shuffled, ordered, 1-element and empty lists with border pixels."""
+    x, y = 23, 19
+    scene, labels = synth.small_scene(x, y, z, 5, dtype)
+    di = prep.scan_labels(labels, x, y)
+    tr9, te9, oh, _ = prep.build_index(labels, di, x, y)
+    prep.shuffle(tr9, oh, 3)
+    orc.srand(2)
+    params = dev(orc.init_params_f32(z) if dtype == np.float32 else orc.init_params_f64(z, 0))
+    sc = dev(scene)
+    for idx in (tr9, te9, tr9[:1], tr9[:7], tr9[:0]):
+        idx_d = dev(np.ascontiguousarray(idx.reshape(-1, 9)))
+        p1, a1 = ops.forward(params, ops.gather(sc, idx_d, x, y, z), z)
+        p2, a2 = ops.forward_scene(params, sc, idx_d, x, y, z)
+        assert torch.equal(p1, p2) and torch.equal(a1, a2)
+    # and against the oracle, through the cubes the oracle gathers itself
+    cubes = orc.gather(scene, tr9, x, y, z)
+    p_ref, a_ref = orc.forward(params.cpu().numpy(), cubes, z)
+    p2, a2 = ops.forward_scene(params, sc, dev(tr9), x, y, z)
+    assert relerr(p2.cpu().numpy(), p_ref) < (1e-5 if dtype == np.float32 else 1e-12)
+
+
 @pytest.mark.parametrize("dtype,z,n", [(np.float64, 176, 67), (np.float32, 200, 130), (np.float32, 103, 33),
                                        (np.float64, 21, 5), (np.float32, 224, 17), (np.float64, 22, 3)])
 def test_forward_matches_oracle(dtype, z, n):
