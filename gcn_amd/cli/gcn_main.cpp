@@ -11,6 +11,8 @@
 //   --variant=V  --seed=N (default: time, like the reference)  --epochs=N (300)
 //   --batch=N (100)  --model=PATH (load weights instead of initialising)
 //   --exchange=rccl|oneshot (multi-GPU form: gradient exchange, default rccl)
+//   --tail=keep|drop (single GPU MBGD: train the last T % B samples as a short batch; default drop)
+//   --preprocess (write traindata.mat / testdata.mat like pre-treatment/preprocess048 and stop)
 //   --infer (skip training; needs --model)
 //   --mat-info=FILE, --mat-rewrite=SRC:DST   MAT-file utilities, no GPU needed
 // stdout keeps the reference's lines and spacing so tools/run.sh's field cuts work.
@@ -57,7 +59,7 @@ struct Options {
     std::string variant = "mbgd_fp32", model;
     long seed = -1;
     int epochs = 300, batch = 100;
-    bool infer = false;
+    bool infer = false, preprocess = false, keep_tail = false;
     std::string exchange = "rccl";   // multi-GPU gradient exchange: rccl | oneshot
     std::vector<std::string> pos;
 };
@@ -149,7 +151,7 @@ struct Samples {
     std::vector<int> train_idx9, test_idx9, onehot, test_labels;
 };
 
-Samples build_samples(const std::vector<double> &labels, int x, int y, unsigned seed)
+Samples build_samples(const std::vector<double> &labels, int x, int y, unsigned seed, bool shuffle = true)
 {
     Samples s;
     std::vector<int> data_index((size_t)x * y);
@@ -166,7 +168,7 @@ Samples build_samples(const std::vector<double> &labels, int x, int y, unsigned 
     s.test_labels.resize(s.n_test);
     CK(ccnn_host_build_index(labels.data(), data_index.data(), n, x, y, s.train_idx9.data(), s.test_idx9.data(),
                              s.onehot.data(), s.test_labels.data()));
-    CK(ccnn_host_shuffle(s.train_idx9.data(), s.onehot.data(), s.n_train, seed));
+    if (shuffle) CK(ccnn_host_shuffle(s.train_idx9.data(), s.onehot.data(), s.n_train, seed));
     return s;
 }
 
@@ -251,6 +253,9 @@ double run(const Options &opt, const Variant &v, const matio::Array &scene_a, co
     const long slice = nd > 1 ? s.n_train / nd : s.n_train;
     const int sub_b = v.sgd ? 1 : B / nd;
     const long batch_num = v.sgd ? 0 : s.n_train / B;
+    // --tail=keep (single GPU): the last T % B samples train as a short final batch averaged over its
+    // own size (hyper_version_MBGD.cu:780, 794-796); default: dropped (gcn_mbgd_fp64.cu:895)
+    const int tail = (!v.sgd && !multi && opt.keep_tail) ? (int)(s.n_train % B) : 0;
     std::vector<Device<T>> dev(nd);
     for (int k = 0; k < nd; k++) {
         Device<T> &D = dev[k];
@@ -271,7 +276,7 @@ double run(const Options &opt, const Variant &v, const matio::Array &scene_a, co
         }
         D.params = to_device(params_t);
         D.grad = dmalloc<T>(d.nparams);
-        D.loss = dmalloc<double>(std::max<long>(batch_num, 1) * std::max(sub_b, 1));
+        D.loss = dmalloc<double>(std::max<long>(batch_num + 1, 1) * std::max(sub_b, 1));
         D.ws_bytes = v.sgd ? ccnn_sgd_workspace_bytes(z) : ccnn_mbgd_workspace_bytes(sub_b, z, (int)sizeof(T));
         CK(hipMalloc(&D.ws, D.ws_bytes));
     }
@@ -309,7 +314,7 @@ double run(const Options &opt, const Variant &v, const matio::Array &scene_a, co
         ccnn_lr_sched_t sched;
         CK(ccnn_host_sched_init(&sched, v.fifo, v.f32));
         fprintf(stdout, "%s] lr = %lf\n", head, lr);
-        std::vector<double> loss_h((size_t)std::max<long>(batch_num, 1) * std::max(sub_b, 1));
+        std::vector<double> loss_h((size_t)std::max<long>(batch_num + 1, 1) * std::max(sub_b, 1));
         for (int iter = 0; iter < opt.epochs; iter++) {
             Clock::time_point t_it = Clock::now();
             double single_rate = 0;
@@ -364,15 +369,25 @@ double run(const Options &opt, const Variant &v, const matio::Array &scene_a, co
                         }
                     }
                 }
+                if (tail) {
+                    Device<T> &D = dev[0];
+                    double *lv = D.loss + batch_num * sub_b;
+                    if (v.f32)
+                        CK(ccnn_mbgd_step_f32((float *)D.params, (const float *)D.cubes, D.onehot, batch_num * sub_b, tail,
+                                              z, (float)lr, lv, D.ws, D.ws_bytes, D.st));
+                    else
+                        CK(ccnn_mbgd_step_f64((double *)D.params, (const double *)D.cubes, D.onehot, batch_num * sub_b,
+                                              tail, z, lr, lv, D.ws, D.ws_bytes, D.st));
+                }
                 // one D2H per device per epoch; host adds the per-sample losses in order
                 float loss32 = 0;
                 double loss64 = 0;
                 for (int k = 0; k < nd; k++) {
                     CK(hipSetDevice(dev[k].id));
-                    CK(hipMemcpyAsync(loss_h.data(), dev[k].loss, sizeof(double) * batch_num * sub_b,
+                    CK(hipMemcpyAsync(loss_h.data(), dev[k].loss, sizeof(double) * (batch_num * sub_b + tail),
                                       hipMemcpyDeviceToHost, dev[k].st));
                     CK(hipStreamSynchronize(dev[k].st));
-                    for (long j = 0; j < batch_num * sub_b; j++) {
+                    for (long j = 0; j < batch_num * sub_b + tail; j++) {
                         if (v.f32) loss32 = loss32 + loss_h[j];   // `float loss` (gcn_mbgd_fp32.cu:882, 1027)
                         else loss64 = loss64 + loss_h[j];
                     }
@@ -427,6 +442,53 @@ double run(const Options &opt, const Variant &v, const matio::Array &scene_a, co
     return s.n_test ? (double)right / s.n_test : 0.0;
 }
 
+// `gcn --preprocess DATASET.mat device_id`: the stand-alone gather of pre-treatment/preprocess048.cu
+// (:66-262): cubes of all labelled pixels in scan order (no shuffle), fp64, written as
+// testdata.mat {data (9z x test_size), labels (test_size x 1)} and
+// traindata.mat {data (9z x train_size), labels (13 x train_size, one-hot)}.
+int preprocess_dump(const matio::Array &scene_a, const std::vector<double> &labels, int x, int y, int z, int device)
+{
+    Clock::time_point t0 = Clock::now();
+    ccnn_dims_t d;
+    CK(ccnn_get_dims(z, &d));
+    Samples s = build_samples(labels, x, y, 0, false);
+    fprintf(stdout, "train_size:%d  test_size:%d\n", s.n_train, s.n_test);
+    fprintf(stdout, "Index computing completed!\n");
+    std::vector<double> scene((size_t)x * y * z);
+    for (size_t i = 0; i < scene.size(); i++) scene[i] = scene_a.is_single ? (double)scene_a.f32[i] : scene_a.f64[i];
+    CK(hipSetDevice(device));
+    double *scene_d = to_device(scene);
+    std::vector<double> train((size_t)s.n_train * d.cube), test((size_t)s.n_test * d.cube);
+    struct Part {
+        const std::vector<int> *idx;
+        int n;
+        std::vector<double> *out;
+    } parts[2] = {{&s.train_idx9, s.n_train, &train}, {&s.test_idx9, s.n_test, &test}};
+    for (auto &p : parts) {
+        if (p.n == 0) continue;
+        int *idx_d = to_device(*p.idx);
+        double *out_d = dmalloc<double>((size_t)p.n * d.cube);
+        CK(ccnn_gather_f64(scene_d, idx_d, p.n, x, y, z, out_d, nullptr, 0, nullptr));   // scan order: no ordering pass
+        CK(hipMemcpy(p.out->data(), out_d, sizeof(double) * p.out->size(), hipMemcpyDeviceToHost));
+        CK(hipFree(out_d));
+        CK(hipFree(idx_d));
+    }
+    CK(hipFree(scene_d));
+    if (train.size() >= 4) fprintf(stdout, "Processed train data:%lf %lf %lf %lf\n", train[0], train[1], train[2], train[3]);
+    if (test.size() >= 4) fprintf(stdout, "Processed test data:%lf %lf %lf %lf\n", test[0], test[1], test[2], test[3]);
+    std::vector<double> onehot(s.onehot.begin(), s.onehot.end()), tl(s.test_labels.begin(), s.test_labels.end());
+    std::string err;
+    if (!matio::write("testdata.mat", {{"data", (size_t)d.cube, (size_t)s.n_test, test.data()},
+                                       {"labels", (size_t)s.n_test, 1, tl.data()}}, err) ||
+        !matio::write("traindata.mat", {{"data", (size_t)d.cube, (size_t)s.n_train, train.data()},
+                                        {"labels", (size_t)CCNN_CLASSES, (size_t)s.n_train, onehot.data()}}, err)) {
+        fprintf(stderr, "%s\n", err.c_str());
+        return 1;
+    }
+    fprintf(stdout, "Using time of preprocessing:%lfs\n", secs(t0));
+    return 0;
+}
+
 // File utilities that need no GPU: list a MAT-file's numeric variables, and
 // optionally write its real double 2-D matrices back out with this writer.
 int mat_info(const std::string &src, const std::string &dst)
@@ -477,6 +539,9 @@ int main(int argc, char *argv[])
         else if (a.rfind("--exchange=", 0) == 0) opt.exchange = a.substr(11);
         else if (a.rfind("--model=", 0) == 0) opt.model = a.substr(8);
         else if (a == "--infer") opt.infer = true;
+        else if (a == "--preprocess") opt.preprocess = true;
+        else if (a == "--tail=keep") opt.keep_tail = true;
+        else if (a == "--tail=drop") opt.keep_tail = false;
         else opt.pos.push_back(a);
     }
     if (const char *e = getenv("CCNN_SEED"))
@@ -563,6 +628,7 @@ int main(int argc, char *argv[])
     std::vector<double> labels(lab->numel());
     for (size_t i = 0; i < labels.size(); i++) labels[i] = lab->is_single ? (double)lab->f32[i] : lab->f64[i];
 
+    if (opt.preprocess) return preprocess_dump(*scene, labels, x, y, z, devices[0]);
     const double correct = v->f32 ? run<float>(opt, *v, *scene, labels, x, y, z, devices)
                                   : run<double>(opt, *v, *scene, labels, x, y, z, devices);
     fprintf(stdout, "Accuracy: %.3f%% \n", correct * 100);

@@ -107,7 +107,7 @@ class MbgdStepper:
 
 
 def fit_mbgd(params, cubes, onehot, z, batch=100, lr=None, min_err=None, max_iter=300, fifo_init=None,
-             group=None, distributed=False, train_size=None, stepper=None, log=None):
+             group=None, distributed=False, train_size=None, stepper=None, log=None, keep_tail=False):
     """Minibatch epochs; params updated in place (identically on every rank).
 
     Single process: cubes/onehot hold all T training samples.
@@ -115,6 +115,9 @@ def fit_mbgd(params, cubes, onehot, z, batch=100, lr=None, min_err=None, max_ite
     RANK'S slice of floor(T/n) samples (hyper_version_mGPU_MBGD.cu:934-940), every step
     consumes floor(batch/n) of them, gradients are all-reduced and every rank applies
     w -= lr * sum / batch (fp64) or w -= lr * sum (fp32).  train_size = T.
+    keep_tail (single process only): the last T % batch samples form a short final batch whose
+    mean is taken over its own size (hyper_version_MBGD.cu:780, 794-796) instead of being
+    dropped (gcn_mbgd_fp64.cu:895).
     """
     f32 = params.dtype == torch.float32
     lr = (0.04 if f32 else 0.5) if lr is None else lr
@@ -143,21 +146,26 @@ def fit_mbgd(params, cubes, onehot, z, batch=100, lr=None, min_err=None, max_ite
         except Exception:   # raised on every rank alike (see NodeComm)
             node = None
     sched = prep.LrSchedule(fifo_init, use_float=f32)
-    loss_d = torch.zeros((max(batch_num, 1), sub_b), dtype=torch.float64, device=params.device)
+    steps = [(i0 * sub_b, sub_b) for i0 in range(batch_num)]
+    if keep_tail and T % batch:
+        if comm.world != 1:
+            raise ValueError("keep_tail is a single-process option")
+        steps.append((batch_num * batch, T % batch))
+    loss_d = torch.zeros((max(len(steps), 1), sub_b), dtype=torch.float64, device=params.device)
     hist = History()
     for it in range(max_iter):
-        for i0 in range(batch_num):
-            first = i0 * sub_b
+        for i0, (first, nb) in enumerate(steps):
             if comm.world == 1 and stepper is None:
-                st.step_fused(first, sub_b, lr, loss_d[i0])
+                st.step_fused(first, nb, lr, loss_d[i0])
             elif node is not None:
-                ops.mbgd_step(params, cubes, onehot, first, sub_b, z, lr, loss_values=loss_d[i0], workspace=st.ws,
+                ops.mbgd_step(params, cubes, onehot, first, nb, z, lr, loss_values=loss_d[i0], workspace=st.ws,
                               comm=node, divisor=batch)
             else:
-                g = comm.all_reduce(st.grad(first, sub_b, loss_d[i0]))
-                st.update(g, lr, batch)
+                g = comm.all_reduce(st.grad(first, nb, loss_d[i0]))
+                st.update(g, lr, batch if nb == sub_b else nb)
         # one D2H per epoch; the host adds the per-sample losses in sample order
-        lv = loss_d[:batch_num].cpu().numpy().ravel()
+        lv_all = loss_d[:len(steps)].cpu().numpy()
+        lv = np.concatenate([lv_all[i, :nb] for i, (_, nb) in enumerate(steps)]) if steps else lv_all.ravel()[:0]
         if f32:
             acc = np.float32(0)                               # `float loss` (gcn_mbgd_fp32.cu:882, 1027)
             for v in lv:

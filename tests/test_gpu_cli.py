@@ -35,7 +35,7 @@ def run_gcn(tmp_path, args):
     return r.stdout
 
 
-def oracle_run(scene, labels, dtype, B, lr, epochs, sgd=False, fifo=1.0):
+def oracle_run(scene, labels, dtype, B, lr, epochs, sgd=False, fifo=1.0, keep_tail=False):
     d = orc.dims(Z)
     di = orc.scan_labels(labels, X, Y)
     tr9, te9, onehot, tl = orc.build_index(labels, di, X, Y)
@@ -52,8 +52,8 @@ def oracle_run(scene, labels, dtype, B, lr, epochs, sgd=False, fifo=1.0):
             rate = orc.sgd_f64(p, train, onehot, 0, T, Z, float(cur)) / T
         else:
             tot = dtype(0) if dtype == np.float32 else 0.0
-            for i0 in range(T // B):
-                lv, _, _ = orc.mbgd_step(p, train, onehot, i0 * B, B, Z, cur, want_grad=False)
+            for first in range(0, T if keep_tail else T - T % B, B):
+                lv, _, _ = orc.mbgd_step(p, train, onehot, first, min(B, T - first), Z, cur, want_grad=False)
                 for v in lv:
                     tot = dtype(np.float64(tot) + v) if dtype == np.float32 else tot + v
             rate = float(tot) / T
@@ -127,6 +127,36 @@ def test_multi_gpu_form_with_one_device(tmp_path, extra):
     losses, acc_line, _ = parse(out)
     assert np.allclose(losses, l_ref, rtol=2e-5, atol=1e-6)
     assert abs(float(acc_line.split(" ")[9].rstrip("%")) - 100 * acc_ref) <= 0.1 + 1e-9
+
+
+def test_tail_batch_kept(tmp_path):
+    """--tail=keep trains the last T % B samples as a short batch (hyper_version_MBGD.cu:780, 794-796)."""
+    path, scene, labels = make_dataset(tmp_path, np.float64)
+    B, epochs = 32, 2
+    out = run_gcn(tmp_path, ["--variant=mbgd_fp64", f"--seed={SEED}", f"--epochs={epochs}", f"--batch={B}",
+                             "--tail=keep", path, "0"])
+    _, l_ref, acc_ref, _ = oracle_run(scene, labels, np.float64, B, 0.5, epochs, keep_tail=True)
+    _, l_drop, _, _ = oracle_run(scene, labels, np.float64, B, 0.5, epochs)
+    losses, acc_line, _ = parse(out)
+    assert np.allclose(losses, l_ref, rtol=2e-5, atol=1e-6) and not np.allclose(l_ref, l_drop, rtol=1e-4)
+    assert abs(float(acc_line.split(" ")[9].rstrip("%")) - 100 * acc_ref) <= 0.1 + 1e-9
+
+
+def test_preprocess_dump(tmp_path):
+    """`gcn --preprocess DATASET.mat 0` writes what pre-treatment/preprocess048.cu:240-261 writes:
+    cubes of all labelled pixels in scan order, one-hot training labels, plain test labels."""
+    path, scene, labels = make_dataset(tmp_path, np.float64)
+    out = run_gcn(tmp_path, ["--preprocess", path, "0"])
+    di = orc.scan_labels(labels, X, Y)
+    tr9, te9, onehot, tl = orc.build_index(labels, di, X, Y)
+    assert f"train_size:{len(tr9)}  test_size:{len(te9)}" in out
+    tr = sio.loadmat(str(tmp_path / "traindata.mat"))
+    te = sio.loadmat(str(tmp_path / "testdata.mat"))
+    assert tr["data"].shape == (9 * Z, len(tr9)) and te["data"].shape == (9 * Z, len(te9))
+    assert np.array_equal(tr["data"].T, orc.gather(scene, tr9, X, Y, Z))          # bit-exact copy
+    assert np.array_equal(te["data"].T, orc.gather(scene, te9, X, Y, Z))
+    assert np.array_equal(tr["labels"].T, onehot.astype(np.float64))
+    assert np.array_equal(te["labels"].ravel(), tl.astype(np.float64))
 
 
 def test_argument_errors(tmp_path):

@@ -116,3 +116,30 @@ def test_training_learns_a_learnable_scene(tdt, lr):
         assert hist.loss[-1] < hist.loss[0]
     acc = train.evaluate(got["params"], got["test_cubes"], got["test_labels"], z)
     assert acc > 0.5
+
+
+def test_fit_mbgd_keep_tail_batch():
+    """keep_tail: the last T % B samples train as a short batch averaged over its own size
+    (hyper_version_MBGD.cu:780, 794-796) instead of being dropped."""
+    x, y, z, seed, epochs, B = 24, 20, 60, 77, 2, 32
+    scene, labels = synth.small_scene(x, y, z, 3)
+    d = orc.dims(z)
+    ref = oracle_prepare(scene, labels, x, y, z, np.float64, seed, d.pout * B)
+    got = train.prepare(scene, labels, x, y, z, torch.float64, seed, pool_bias_draws=d.pout * B)
+    T = len(ref["onehot"])
+    assert T % B != 0
+    hist = train.fit_mbgd(got["params"], got["train_cubes"], got["onehot"], z, batch=B, lr=0.5, min_err=0.0,
+                          max_iter=epochs, keep_tail=True)
+    p = ref["params"].copy()
+    cur = 0.5
+    sched = orc.Sched(np.float64, 1.0)
+    for ep in range(epochs):
+        tot = 0.0
+        for first in range(0, T, B):
+            nb = min(B, T - first)
+            lv, _, _ = orc.mbgd_step(p, ref["train"], ref["onehot"], first, nb, z, cur, want_grad=False)
+            for v in lv:
+                tot = tot + v
+        assert abs(hist.loss[ep] - tot / T) <= 1e-11 * abs(tot / T)
+        _, cur = sched.step(tot / T, cur)
+    assert relerr(got["params"].cpu().numpy(), p) < 1e-11
