@@ -215,6 +215,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dts = t.item()
     infer_scene_pps = world * te_n * reps / dts
+    # every pixel of the scene (this rank's 1/N of them), again straight from the scene
+    all_lab = np.ones(x * y, dtype=np.float64)
+    a_tr9, a_te9, _, _ = prep.build_index(all_lab, prep.scan_labels(all_lab, x, y), x, y)
+    all9 = np.concatenate([a_tr9, a_te9])
+    fs_n = len(all9) // world
+    all_idx_d = torch.from_numpy(np.ascontiguousarray(all9[rank * fs_n:(rank + 1) * fs_n])).to(dev)
+    ops.forward_scene(params, scene_d, all_idx_d, x, y, z, want_probs=False, workspace=fws)
+    fs_reps = max(1, int(2e6 // max(fs_n, 1)))
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(fs_reps):
+        ops.forward_scene(params, scene_d, all_idx_d, x, y, z, want_probs=False, workspace=fws)
+    fence()
+    dtf = time.perf_counter() - t1
+    if world > 1:
+        t = torch.tensor([dtf], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dtf = t.item()
+    infer_full_pps = world * fs_n * fs_reps / dtf
+    del all_idx_d
 
     # ---- fp64 per-sample SGD on the same cubes (sequential by definition: replicas only, rank 0 reports)
     sgd_pps = None
@@ -319,6 +339,7 @@ def main():
                        "replicas_identical": replicas_identical},
             "infer_pixels_per_s": round(infer_pps, 1),
             "infer_from_scene_pixels_per_s": round(infer_scene_pps, 1),
+            "infer_full_scene_pixels_per_s": round(infer_full_pps, 1),
             "sgd_fp64_pixels_per_s": round(sgd_pps, 1),
             "roofline": roof,
             "cpu_baseline": cpu,

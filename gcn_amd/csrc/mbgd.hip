@@ -21,6 +21,18 @@
 #include "comm.h"
 #include "profile.h"
 
+// Diagnostic builds only (-DCCNN_FB_TIMING): workgroup 5 of sample_fwd_bwd stamps the wall clock
+// (100 MHz) at FB_TICK(k); ccnn_debug_fb_ticks() returns the stamps of the last launch.
+#ifdef CCNN_FB_TIMING
+__device__ unsigned long long g_fb_ticks[32];
+#define FB_TICK(k)                                                             \
+    do {                                                                       \
+        if (blockIdx.x == 5 && threadIdx.x == 0) g_fb_ticks[k] = wall_clock64(); \
+    } while (0)
+#else
+#define FB_TICK(k) do { } while (0)
+#endif
+
 #ifndef CCNN_STOP_PHASE
 #define CCNN_STOP_PHASE 0   // diagnostic builds only: end sample_fwd_bwd after phase N
 #endif
@@ -34,7 +46,7 @@ __host__ __device__ inline int up4(int v) { return (v + 3) & ~3; }
 struct FusedLayout {
     int cube, wl, a0, pl, dp, a1, d1, es, ps, d2, lta, ltb, total;   // element offsets / count
     int ldd, ks;
-    size_t px_off, bytes;
+    size_t px_off, lab_off, bytes;
 };
 
 template <typename T>
@@ -61,7 +73,8 @@ __host__ __device__ inline FusedLayout fused_layout(int re, int mre)
     L.ltb = o;  o += 16;
     L.total = o;
     L.px_off = (size_t)o * sizeof(T);
-    L.bytes = L.px_off + (size_t)up4(pout) * sizeof(int);
+    L.lab_off = L.px_off + (size_t)up4(pout) * sizeof(int);   // 16 ints: the sample's one-hot labels
+    L.bytes = L.lab_off + 16 * sizeof(int);
     return L;
 }
 
@@ -153,7 +166,10 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
     const int col = lane & 15;
     const int re = d.re, mre = d.mre, pout = d.pout;
     const long row = blockIdx.x;
-    const int *lab = onehot + (first + row) * O;
+    FB_TICK(0);
+    int *lab = reinterpret_cast<int *>(smem + L.lab_off);
+    // the labels are needed deep in the dependent chain: fetch them with the first loads
+    const int lab_g = onehot[(first + row) * O + min(tid, O - 1)];
 
     // ---- forward: conv + tanh + pool ------------------------------------------------
     // Issue every global load this phase needs (filters, cube, and the small output-layer
@@ -178,6 +194,7 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
     const T b2v = params[d.off_b2 + min(o8, O - 1)];
     const T bias0 = params[d.off_b0 + col];
     const T bias1 = params[d.off_b0 + min(16 + col, F - 1)];
+    if (tid < O) lab[tid] = lab_g;
     for (int e = d.cube + tid; e < conv_cube_pad(re); e += 256) cube[e] = 0;
     for (int e = tid; e < WL_LEN; e += 256) wl[e] = 0;
     stage<8, 256>(cubes + (first + row) * (long)d.cube, d.cube, tid, [&](int e, T v) { cube[e] = v; });
@@ -192,6 +209,7 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
         }
     }
     __syncthreads();
+    FB_TICK(1);
 #if CCNN_STOP_PHASE == 1
     return;
 #endif
@@ -200,6 +218,7 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
         px[f * mre + m] = bt;
     });
     __syncthreads();
+    FB_TICK(2);
 #if CCNN_STOP_PHASE == 2
     return;
 #endif
@@ -242,6 +261,7 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
         if (qv) reinterpret_cast<V *>(z1p + g * H)[q] = acc;
     }
     __syncthreads();
+    FB_TICK(3);
 #if CCNN_STOP_PHASE == 3
     return;
 #endif
@@ -256,6 +276,7 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
     }
     __syncthreads();
 
+    FB_TICK(4);
     // ---- output layer, softmax, loss, delta2, delta1 ---------------------------------
     {
         T mid = 0;
@@ -270,6 +291,7 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
         if (o8 < O && j8 == 0) es[o8] = rexp(mid + b2v);
     }
     __syncthreads();
+    FB_TICK(5);
     if (tid < O) {
         const T p = es[tid] / tree13(es);
         ps[tid] = p;
@@ -282,6 +304,7 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
     // the filters are dead: clear their region for the scattered deltas
     for (int e = tid; e < 2 * L.ldd; e += 256) wl[e] = 0;
     __syncthreads();
+    FB_TICK(6);
     if (tid == 255) loss_values[row] = loss_sum(lta, ltb, lab);
     if (tid < H) {
         // bp_fully_connect(out -> hidden), gcn_mbgd_fp64.cu:416-434: 13-wide tree
@@ -293,6 +316,7 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
         d1_g[row * H + tid] = dv;
     }
     __syncthreads();
+    FB_TICK(7);
 #if CCNN_STOP_PHASE == 4
     return;
 #endif
@@ -335,6 +359,7 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
         }
     }
     __syncthreads();
+    FB_TICK(8);
 #if CCNN_STOP_PHASE == 5
     return;
 #endif
@@ -342,6 +367,7 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
     // ---- conv gradient tile of this sample -------------------------------------------
     T *out = slab + row * (long)(F * K + F);
     conv_bwd_tiles<T>(cube, wl, L.ldd, L.ks, re, out, lane, wave);
+    FB_TICK(9);
     if (tid < F) {
         // bias path: at a winner the conv output equals the pooled value, so the
         // reference's second tanh' (gcn_mbgd_fp64.cu:487-488) needs only pl
@@ -352,6 +378,7 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
         }
         out[F * K + tid] = mid1 / re;
     }
+    FB_TICK(10);
 }
 
 // ---------------------------------------------------------------------------
@@ -628,6 +655,13 @@ int mbgd_impl(const T *params, const T *cubes, const int *onehot, long first, in
 }  // namespace ccnn
 
 using namespace ccnn;
+
+#ifdef CCNN_FB_TIMING
+extern "C" int ccnn_debug_fb_ticks(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fb_ticks), sizeof(unsigned long long) * 32);
+}
+#endif
 
 extern "C" {
 

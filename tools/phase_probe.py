@@ -16,3 +16,11 @@ for i in range(50): ops.mbgd_step(params, cubes, onehot, (i % 8) * B, B, z, 0.0,
 torch.cuda.synchronize(); t0 = time.perf_counter(); n = 500
 for i in range(n): ops.mbgd_step(params, cubes, onehot, (i % 8) * B, B, z, 0.0, loss_values=lv, workspace=ws)
 torch.cuda.synchronize(); print(os.environ.get("CCNN_LIB_PATH", "default"), f"{(time.perf_counter() - t0) / n * 1e6:.1f} us/step")
+if os.environ.get("CCNN_FB_TIMING"):
+    import ctypes as C
+    lib = C.CDLL(os.environ["CCNN_LIB_PATH"])
+    t = (C.c_ulonglong * 32)()
+    torch.cuda.synchronize()
+    assert lib.ccnn_debug_fb_ticks(t) == 0
+    names = ["stage", "conv+pool", "fc1", "a1", "out layer", "softmax", "delta1", "dpool", "conv_bwd", "bias+tail"]
+    print("  ".join(f"{names[k]}={(t[k + 1] - t[k]) * 10}ns" for k in range(10)), f"total={(t[10] - t[0]) * 10}ns")
