@@ -264,13 +264,44 @@ __device__ __forceinline__ void pool_tile(const Mma<double>::acc_t &acc, double 
 // put(sample, f, m, value, winning position).
 template <typename T, typename Put>
 __device__ __forceinline__ void conv_pool_tiles(const T *cube, int cube_stride, int nsamp, const T *wl, int re,
-                                                T bias0, T bias1, int lane, int wave, Put put)
+                                                T bias0, T bias1, int lane, int wave, Put put, int nwaves = 4,
+                                                bool split = false)
 {
     const int col = lane & 15, kq = lane >> 4;
     const int mt = conv_mtiles(re);
     const T *bp0 = wl + kq * LDWK + col;
     const T *bp1 = bp0 + WL_TILE;
-    for (int job = wave; job < nsamp * mt; job += 4) {
+    if (split) {
+        // one filter half per job: twice the jobs for workgroups with more waves than position tiles
+        for (int job = wave; job < 2 * nsamp * mt; job += nwaves) {
+            const int half = job & 1, pj = job >> 1;
+            const int sidx = pj / mt, tile = pj - sidx * mt;
+            const T *ap = cube + sidx * cube_stride + WSTEP * (tile * 16 + col) + kq;
+            const T *bp = half ? bp1 : bp0;
+            typename Mma<T>::acc_t acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};   // two chains: even / odd k-steps
+            int s = 0;
+            for (; s + 4 <= KSTEPS0; s += 4) {
+                T a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    a[u] = ap[4 * (s + u)];
+                    b[u] = bp[4 * (s + u) * LDWK];
+                }
+                acc = Mma<T>::mma(a[0], b[0], acc);
+                acc2 = Mma<T>::mma(a[1], b[1], acc2);
+                acc = Mma<T>::mma(a[2], b[2], acc);
+                acc2 = Mma<T>::mma(a[3], b[3], acc2);
+            }
+            for (; s < KSTEPS0; s++) acc = Mma<T>::mma(ap[4 * s], bp[4 * s * LDWK], acc);
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[r] += acc2[r];
+            auto put1 = [&](int f, int m, T v, int bt) { put(sidx, f, m, v, bt); };
+            if (half) pool_tile(acc, bias1, 16 + col, 16 + col < F, tile * 16, re, lane, put1);
+            else pool_tile(acc, bias0, col, true, tile * 16, re, lane, put1);
+        }
+        return;
+    }
+    for (int job = wave; job < nsamp * mt; job += nwaves) {
         const int sidx = job / mt, tile = job - sidx * mt;
         const T *ap = cube + sidx * cube_stride + WSTEP * (tile * 16 + col) + kq;
         typename Mma<T>::acc_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};

@@ -57,7 +57,7 @@ __host__ __device__ inline FusedLayout fused_layout(int re, int mre)
     L.ks = (re + 3) >> 2;
     L.ldd = 4 * L.ks * LDWK;   // one position-major delta tile [4 ks][16 filters]
     const int wl_len = 2 * L.ldd > WL_LEN ? 2 * L.ldd : WL_LEN;   // filters, later the scattered deltas
-    const int a0_len = 8 * H;   // FC1 partial sums [G][100]
+    const int a0_len = 32 * H;   // FC1 partial sums [G][100], G <= 32 row groups
     int o = 0;
     L.cube = o; o += up4(conv_cube_pad(re));
     L.wl = o;   o += up4(wl_len);
@@ -80,44 +80,48 @@ __host__ __device__ inline FusedLayout fused_layout(int re, int mre)
 
 // Conv weight gradient of one sample as an MFMA product:
 // dW0[f][tap] = sum_t delta[f][t] cube[18 t + tap] / re  ([20 x re] x [re x 171]),
-// 2 filter tiles x 11 tap tiles, wave w owns tap tiles w, w+4, w+8.
+// 2 filter tiles x 11 tap tiles, wave w of NW owns tap tiles w, w+NW, ..
 // delta is two position-major tiles [4 ks][16] (tile_len apart; filters 20..31 and positions
 // >= re zero) so that, like the forward filter tiles, A-fragment reads are bank-conflict free;
 // cube zero-padded; out = [F][K].
-template <typename T>
+template <typename T, int NW>
 __device__ __forceinline__ void conv_bwd_tiles(const T *cube, const T *delta, int tile_len, int ks, int re,
                                                T *__restrict__ out, int lane, int wave)
 {
+    constexpr int NTT = (11 + NW - 1) / NW;   // tap tiles per wave: wave w owns w, w+NW, ..  (171 taps = 11 tiles)
     const int col = lane & 15, kq = lane >> 4;
     const T *ap0 = delta + kq * LDWK + col;
     const T *ap1 = ap0 + tile_len;
-    const bool t2 = wave + 8 < 11;   // 171 taps = 11 tiles
-    const T *bp0 = cube + WSTEP * kq + wave * 16 + col;
-    const T *bp1 = bp0 + 64;
-    const T *bp2 = bp0 + (t2 ? 128 : 0);
-    typename Mma<T>::acc_t c00 = {0, 0, 0, 0}, c01 = c00, c02 = c00, c10 = c00, c11 = c00, c12 = c00;
+    const T *bp[NTT];
+    bool live[NTT];
+#pragma unroll
+    for (int j = 0; j < NTT; j++) {
+        live[j] = wave + j * NW < 11;
+        bp[j] = cube + WSTEP * kq + (live[j] ? wave + j * NW : wave) * 16 + col;
+    }
+    typename Mma<T>::acc_t c0[NTT], c1[NTT];
+#pragma unroll
+    for (int j = 0; j < NTT; j++) c0[j] = c1[j] = typename Mma<T>::acc_t{0, 0, 0, 0};
     auto kstep2 = [&](int s, int n) {   // n (1 or 2) k-steps: all operands first, then the MFMAs
-        T a0[2], a1[2], b0[2], b1[2], b2[2];
+        T a0[2], a1[2], b[2][NTT];
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             if (u < n) {
                 a0[u] = ap0[4 * (s + u) * LDWK];
                 a1[u] = ap1[4 * (s + u) * LDWK];
-                b0[u] = bp0[4 * (s + u) * WSTEP];
-                b1[u] = bp1[4 * (s + u) * WSTEP];
-                b2[u] = bp2[4 * (s + u) * WSTEP];
+#pragma unroll
+                for (int j = 0; j < NTT; j++) b[u][j] = bp[j][4 * (s + u) * WSTEP];
             }
         }
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             if (u < n) {
-                c00 = Mma<T>::mma(a0[u], b0[u], c00);
-                c10 = Mma<T>::mma(a1[u], b0[u], c10);
-                c01 = Mma<T>::mma(a0[u], b1[u], c01);
-                c11 = Mma<T>::mma(a1[u], b1[u], c11);
-                if (t2) {
-                    c02 = Mma<T>::mma(a0[u], b2[u], c02);
-                    c12 = Mma<T>::mma(a1[u], b2[u], c12);
+#pragma unroll
+                for (int j = 0; j < NTT; j++) {
+                    if (live[j]) {
+                        c0[j] = Mma<T>::mma(a0[u], b[u][j], c0[j]);
+                        c1[j] = Mma<T>::mma(a1[u], b[u][j], c1[j]);
+                    }
                 }
             }
         }
@@ -134,19 +138,21 @@ __device__ __forceinline__ void conv_bwd_tiles(const T *cube, const T *delta, in
             if (f < F) out[f * K + tap] = acc[r] / re;   // gcn_mbgd_fp64.cu:491
         }
     };
-    emit(c00, 0, wave);
-    emit(c10, 1, wave);
-    emit(c01, 0, wave + 4);
-    emit(c11, 1, wave + 4);
-    if (t2) {
-        emit(c02, 0, wave + 8);
-        emit(c12, 1, wave + 8);
+#pragma unroll
+    for (int j = 0; j < NTT; j++) {
+        if (live[j]) {
+            emit(c0[j], 0, wave + j * NW);
+            emit(c1[j], 1, wave + j * NW);
+        }
     }
 }
 
 // ---------------------------------------------------------------------------
-template <typename T, bool FLIP>
-__global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ params,
+// NT threads per workgroup (one workgroup per sample, one per CU): the per-sample chain is
+// latency-bound, and its two walks over W1 are limited by the bytes a CU keeps in flight, so
+// more waves shorten them even though most other phases cannot use the extra threads.
+template <typename T, bool FLIP, int NT>
+__global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ params,
                                                       const T *__restrict__ cubes,
                                                       const int *__restrict__ onehot, long first,
                                                       ccnn_dims_t d, T *__restrict__ pool_g,
@@ -174,11 +180,12 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
     // ---- forward: conv + tanh + pool ------------------------------------------------
     // Issue every global load this phase needs (filters, cube, and the small output-layer
     // operands used much later) before touching LDS, so one memory round trip covers them.
-    constexpr int NWREG = (F * K + 255) / 256;
+    constexpr int NW = NT / 64;
+    constexpr int NWREG = (F * K + NT - 1) / NT;
     T wreg[NWREG];
 #pragma unroll
     for (int u = 0; u < NWREG; u++) {
-        const int e = u * 256 + tid;
+        const int e = u * NT + tid;
         wreg[u] = params[d.off_w0 + (e < F * K ? e : F * K - 1)];   // clamped: loads stay unconditional
     }
     const T *W2 = params + d.off_w2;
@@ -195,13 +202,13 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
     const T bias0 = params[d.off_b0 + col];
     const T bias1 = params[d.off_b0 + min(16 + col, F - 1)];
     if (tid < O) lab[tid] = lab_g;
-    for (int e = d.cube + tid; e < conv_cube_pad(re); e += 256) cube[e] = 0;
-    for (int e = tid; e < WL_LEN; e += 256) wl[e] = 0;
-    stage<8, 256>(cubes + (first + row) * (long)d.cube, d.cube, tid, [&](int e, T v) { cube[e] = v; });
+    for (int e = d.cube + tid; e < conv_cube_pad(re); e += NT) cube[e] = 0;
+    for (int e = tid; e < WL_LEN; e += NT) wl[e] = 0;
+    stage<8, NT>(cubes + (first + row) * (long)d.cube, d.cube, tid, [&](int e, T v) { cube[e] = v; });
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < NWREG; u++) {
-        const int e = u * 256 + tid;
+        const int e = u * NT + tid;
         if (e < F * K) {
             const int f = e / K, k = e - f * K;
             // the fp32 reference walks the filter backwards in the forward pass (gcn_mbgd_fp32.cu:241-243)
@@ -216,13 +223,13 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
     conv_pool_tiles<T>(cube, 0, 1, wl, re, bias0, bias1, lane, wave, [&](int, int f, int m, T v, int bt) {
         pl[f * mre + m] = v;
         px[f * mre + m] = bt;
-    });
+    }, NW, NW > 4);
     __syncthreads();
     FB_TICK(2);
 #if CCNN_STOP_PHASE == 2
     return;
 #endif
-    for (int o = tid; o < pout; o += 256) pool_g[row * pout + o] = pl[o];
+    for (int o = tid; o < pout; o += NT) pool_g[row * pout + o] = pl[o];
 
     // ---- FC1 forward: z1[n] = sum_p pool[p] W1[n + 100 p] ---------------------------
     // 16-byte vectors along n; QL lanes per W1 row (25 or 50 of them active), G row groups.
@@ -230,7 +237,7 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
     constexpr int VW = Vec16<T>::W;
     constexpr int NQ = H / VW;
     constexpr int QL = NQ <= 32 ? 32 : 64;
-    constexpr int G = 256 / QL;
+    constexpr int G = NT / QL;
     const int q = tid & (QL - 1), g = tid / QL;
     const bool qv = q < NQ;
     const int qc = qv ? q : NQ - 1;
@@ -302,10 +309,9 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
         loss_terms(p, lab[tid], &lta[tid], &ltb[tid]);
     }
     // the filters are dead: clear their region for the scattered deltas
-    for (int e = tid; e < 2 * L.ldd; e += 256) wl[e] = 0;
+    for (int e = tid; e < 2 * L.ldd; e += NT) wl[e] = 0;
     __syncthreads();
     FB_TICK(6);
-    if (tid == 255) loss_values[row] = loss_sum(lta, ltb, lab);
     if (tid < H) {
         // bp_fully_connect(out -> hidden), gcn_mbgd_fp64.cu:416-434: 13-wide tree
         T prod[O];
@@ -320,6 +326,8 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
 #if CCNN_STOP_PHASE == 4
     return;
 #endif
+    // nothing waits for the loss: one thread adds its terms up while the walk below runs
+    if (tid == NT - 1) loss_values[row] = loss_sum(lta, ltb, lab);
 
     // ---- delta at the pooled features + bp_maxpooling scatter -----------------------
     // dpool[p] = (sum_n W1[n + 100 p] d1[n]) (1 + pool)(1 - pool), gcn_mbgd_fp64.cu:416-434, 450-452
@@ -366,7 +374,7 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
 
     // ---- conv gradient tile of this sample -------------------------------------------
     T *out = slab + row * (long)(F * K + F);
-    conv_bwd_tiles<T>(cube, wl, L.ldd, L.ks, re, out, lane, wave);
+    conv_bwd_tiles<T, NW>(cube, wl, L.ldd, L.ks, re, out, lane, wave);
     FB_TICK(9);
     if (tid < F) {
         // bias path: at a winner the conv output equals the pooled value, so the
@@ -391,6 +399,10 @@ __global__ __launch_bounds__(256) void sample_fwd_bwd(const T *__restrict__ para
 //     nb_w0 blocks     dW0 | db0 = sum_b slab[b][.]
 //     nb_w2 blocks     dW2[o + 13 n] = sum_b a1[b][n] d2[b][o]
 //     2 blocks         db1 = sum_b d1        1 block   db2 = sum_b d2
+#ifndef CCNN_FB_THREADS
+#define CCNN_FB_THREADS 512
+#endif
+constexpr int FB_THREADS = CCNN_FB_THREADS;   // threads per sample_fwd_bwd workgroup
 constexpr int GR_THREADS = 512;
 constexpr int GR_TILE_VALUES = 7 * 64 * 4;   // values a dW1 workgroup produces (16 x 112 tile)
 
@@ -622,9 +634,9 @@ int mbgd_impl(const T *params, const T *cubes, const int *onehot, long first, in
     if (ws_bytes < MbgdWs<T>::bytes(B, d)) return CCNN_E_WORKSPACE;
     MbgdWs<T> w(ws, B, d);
     const FusedLayout L = fused_layout<T>(d.re, d.mre);
-    if (int e = allow_smem(sample_fwd_bwd<T, FLIP>, L.bytes)) return e;
+    if (int e = allow_smem(sample_fwd_bwd<T, FLIP, FB_THREADS>, L.bytes)) return e;
     {
-        launch("sample_fwd_bwd", sample_fwd_bwd<T, FLIP>, dim3(B), dim3(256), L.bytes, st, params, cubes, onehot, first,
+        launch("sample_fwd_bwd", sample_fwd_bwd<T, FLIP, FB_THREADS>, dim3(B), dim3(FB_THREADS), L.bytes, st, params, cubes, onehot, first,
                d, w.pool, w.a1, w.d1, w.d2, probs, loss_values, w.slab);
     }
     CCNN_LAUNCH_CHECK();
