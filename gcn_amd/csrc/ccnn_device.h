@@ -31,25 +31,20 @@ struct Mma<double> {
     static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + (r << 2); }
 };
 
-// LDS row strides.  A stride of 15 (mod 32) elements lets 16 lanes that walk rows
-// and the 16 lanes one element further hit distinct banks (one pair excepted); 16
-// (mod 32) does the same for lanes that walk columns of two adjacent rows.
+// LDS row strides.  16 (mod 32) elements lets the 16 lanes that walk a row's columns and the
+// 16 lanes of the next row hit distinct banks; an odd stride does it for lanes that walk rows.
 constexpr int LDWK = 16;    // conv filters: two tap-major tiles [172 taps][16 filters].  Lanes (col, kq)
                             // read tap 4s+kq, filter col: 16 kq + col covers all 32 banks once per
                             // half-wave (a filter-major [f][175] tile costs a 2-way conflict per read).
 constexpr int WL_TILE = 172 * LDWK;  // tap 171 and filters 20..31 are zero
 constexpr int WL_LEN = 2 * WL_TILE;
 __host__ __device__ inline int wl_index(int f, int k) { return (f >> 4) * WL_TILE + k * LDWK + (f & 15); }
-constexpr int LDW1 = 112;   // W1 chunk       [64 p][112], fc1_partial (lanes walk n)
+constexpr int LDW1 = 112;   // W1 chunk       [64 p][112], fc_head_fwd (lanes walk n)
 constexpr int LDP = 79;     // pool tile      [16 b][79]
-constexpr int LDW2 = 111;   // W1 chunk       [64 p][111], fc1_bwd_delta (lanes walk p)
 constexpr int KSTEPS0 = (K + 3) / 4;   // 43 k-steps cover the 171 taps
 
 __host__ __device__ inline int conv_mtiles(int re) { return (re + 15) >> 4; }
 __host__ __device__ inline int conv_cube_pad(int re) { return WSTEP * 16 * conv_mtiles(re) + 160; }
-__host__ __device__ inline int odd_up(int v) { return v | 1; }
-// smallest stride >= n that is 15 (mod 32)
-__host__ __device__ inline int stride15(int n) { return n + ((15 - n) % 32 + 32) % 32; }
 
 // Cooperative global -> LDS staging with U loads in flight per thread: all loads of
 // a round are issued before the first LDS store waits on them (a plain
@@ -80,26 +75,6 @@ struct Vec16 {
     static constexpr int W = 16 / sizeof(T);
     typedef T type __attribute__((ext_vector_type(16 / sizeof(T))));
 };
-template <int U, int NT, typename T, typename Put>
-__device__ __forceinline__ void stage_vec(const T *__restrict__ src, int nvec, int tid, Put put)
-{
-    typedef typename Vec16<T>::type V;
-    const V *vsrc = reinterpret_cast<const V *>(src);
-    for (int base = 0; base < nvec; base += U * NT) {
-        V tmp[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int e = base + u * NT + tid;
-            tmp[u] = vsrc[e < nvec ? e : nvec - 1];
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int e = base + u * NT + tid;
-            if (e < nvec) put(e, tmp[u]);
-        }
-    }
-}
-
 // The reference's ceil-halving tree over 13 values (13 -> 7 -> 4 -> 2 -> 1), in
 // registers: t[i] += t[i+7] (i<6); t[i] += t[i+4] (i<3); t[i] += t[i+2] (i<2); t[0] += t[1].
 template <typename T>

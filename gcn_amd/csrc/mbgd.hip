@@ -33,6 +33,11 @@ __device__ unsigned long long g_fb_ticks[32];
 #define FB_TICK(k) do { } while (0)
 #endif
 
+#ifndef CCNN_FB_WKEEP
+#define CCNN_FB_WKEEP 0   // rounds of W1 rows sample_fwd_bwd keeps in registers between its two walks
+                          // (measured: 0, 1 and 2 rounds take the same time, 4 spill; the walks are not
+                          // bound by their loads)
+#endif
 #ifndef CCNN_STOP_PHASE
 #define CCNN_STOP_PHASE 0   // diagnostic builds only: end sample_fwd_bwd after phase N
 #endif
@@ -247,16 +252,21 @@ __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ param
     // the 128 workgroups pull from different L2 channels instead of queueing on the same lines.
     const int rot = (int)((row * 37) % pout);
     constexpr int UF = 16;   // W1 rows in flight per thread
+    // The backward walk below visits W1 with the same (row, column) -> thread assignment, so the
+    // rows of the first WKEEP rounds can stay in registers and only the rest is read a second time.
+    constexpr int WKEEP = CCNN_FB_WKEEP;
+    V wkeep[WKEEP > 0 ? WKEEP : 1][UF];
+    auto w1_rows = [&](int pb, V(&w)[UF]) {
+#pragma unroll
+        for (int u = 0; u < UF; u++) {
+            int p = min(pb + u * G + g, pout - 1) + rot;   // clamped: loads stay unconditional
+            p = p >= pout ? p - pout : p;
+            w[u] = W1v[(long)p * NQ + qc];
+        }
+    };
     {
         V acc = {};
-        for (int pb = 0; pb < pout; pb += G * UF) {
-            V w[UF];
-#pragma unroll
-            for (int u = 0; u < UF; u++) {
-                int p = min(pb + u * G + g, pout - 1) + rot;   // clamped: loads stay unconditional
-                p = p >= pout ? p - pout : p;
-                w[u] = W1v[(long)p * NQ + qc];
-            }
+        auto fma_rows = [&](int pb, const V(&w)[UF]) {
 #pragma unroll
             for (int u = 0; u < UF; u++) {
                 int p = min(pb + u * G + g, pout - 1) + rot;
@@ -264,6 +274,18 @@ __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ param
                 const T x = (qv && pb + u * G + g < pout) ? pl[p] : T(0);
                 acc += w[u] * x;
             }
+        };
+#pragma unroll
+        for (int it = 0; it < WKEEP; it++) {
+            if (it * G * UF < pout) {
+                w1_rows(it * G * UF, wkeep[it]);
+                fma_rows(it * G * UF, wkeep[it]);
+            }
+        }
+        for (int pb = WKEEP * G * UF; pb < pout; pb += G * UF) {
+            V w[UF];
+            w1_rows(pb, w);
+            fma_rows(pb, w);
         }
         if (qv) reinterpret_cast<V *>(z1p + g * H)[q] = acc;
     }
@@ -338,14 +360,7 @@ __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ param
         static_assert(UF == 16, "reduce_scatter16 handles 16 rows per round");
         const int ru = reduce_scatter_index<QL>(q);          // the row of the round this lane ends up owning
         const bool writer = (q & (QL / 16 - 1)) == 0;        // one lane per owned row stores it
-        for (int pb = 0; pb < pout; pb += G * UF) {
-            V w[UF];
-#pragma unroll
-            for (int u = 0; u < UF; u++) {
-                int p = min(pb + u * G + g, pout - 1) + rot;
-                p = p >= pout ? p - pout : p;
-                w[u] = W1v[(long)p * NQ + qc];
-            }
+        auto dpool_rows = [&](int pb, const V(&w)[UF]) {
             T part[UF];   // d1v is zero in the lanes past the row's end
 #pragma unroll
             for (int u = 0; u < UF; u++) {
@@ -364,6 +379,14 @@ __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ param
                 const int f = p / mre;
                 delta[(f >> 4) * L.ldd + px[p] * LDWK + (f & 15)] = dv;
             }
+        };
+#pragma unroll
+        for (int it = 0; it < WKEEP; it++)
+            if (it * G * UF < pout) dpool_rows(it * G * UF, wkeep[it]);
+        for (int pb = WKEEP * G * UF; pb < pout; pb += G * UF) {
+            V w[UF];
+            w1_rows(pb, w);
+            dpool_rows(pb, w);
         }
     }
     __syncthreads();

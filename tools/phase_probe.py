@@ -3,7 +3,8 @@ import sys, os, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gcn_amd import ops, prep, lib as L
-z, B = int(sys.argv[1]) if len(sys.argv) > 1 else 103, 128
+z = int(sys.argv[1]) if len(sys.argv) > 1 else 103
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 d = L.dims(z)
 rng = np.random.default_rng(0)
 cubes = torch.from_numpy(rng.random((B * 8, 9 * z)).astype(np.float32)).cuda()
@@ -15,7 +16,8 @@ ws = ops.Workspace(); lv = torch.zeros(B, dtype=torch.float64, device="cuda")
 for i in range(50): ops.mbgd_step(params, cubes, onehot, (i % 8) * B, B, z, 0.0, loss_values=lv, workspace=ws)
 torch.cuda.synchronize(); t0 = time.perf_counter(); n = 500
 for i in range(n): ops.mbgd_step(params, cubes, onehot, (i % 8) * B, B, z, 0.0, loss_values=lv, workspace=ws)
-torch.cuda.synchronize(); print(os.environ.get("CCNN_LIB_PATH", "default"), f"{(time.perf_counter() - t0) / n * 1e6:.1f} us/step")
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+print(os.environ.get("CCNN_LIB_PATH", "default"), f"z={z} B={B}: {dt * 1e6:.1f} us/step  {B / dt / 1e6:.2f} M pixels/s")
 if os.environ.get("CCNN_FB_TIMING"):
     import ctypes as C
     lib = C.CDLL(os.environ["CCNN_LIB_PATH"])
