@@ -121,7 +121,8 @@ def test_forward_scene_equals_gather_then_forward(dtype, z):
 
 
 @pytest.mark.parametrize("dtype,z,n", [(np.float64, 176, 67), (np.float32, 200, 130), (np.float32, 103, 33),
-                                       (np.float64, 21, 5), (np.float32, 224, 17), (np.float64, 22, 3)])
+                                       (np.float64, 21, 5), (np.float32, 224, 17), (np.float64, 22, 3),
+                                       (np.float32, 448, 9), (np.float64, 448, 5), (np.float32, 60, 1)])
 def test_forward_matches_oracle(dtype, z, n):
     params, cubes, _ = make_problem(z, n, 100 + z, dtype)
     params = (params * 5).astype(dtype)          # spread the probabilities
@@ -170,7 +171,9 @@ def test_mbgd_golden(golden, dtype, key, lr):
 
 @pytest.mark.parametrize("dtype,z,B,lr", [(np.float64, 176, 100, 0.5), (np.float32, 200, 128, 0.04),
                                           (np.float32, 103, 128, 0.04), (np.float64, 103, 37, 0.5),
-                                          (np.float32, 224, 16, 0.04), (np.float32, 21, 5, 0.04)])
+                                          (np.float32, 224, 16, 0.04), (np.float32, 21, 5, 0.04),
+                                          (np.float64, 448, 6, 0.5), (np.float32, 448, 3, 0.04),
+                                          (np.float64, 60, 1, 0.5)])
 def test_mbgd_steps_match_oracle(dtype, z, B, lr):
     steps = 3
     params, cubes, onehot = make_problem(z, B * steps, 7 + z, dtype)
@@ -230,7 +233,7 @@ def test_sgd_golden(golden):
     assert abs(loss.item() - float(g["sgd_loss"])) < 1e-12 * abs(float(g["sgd_loss"]))
 
 
-@pytest.mark.parametrize("z,n", [(176, 40), (103, 25), (21, 6)])
+@pytest.mark.parametrize("z,n", [(176, 40), (103, 25), (21, 6), (448, 5)])
 def test_sgd_matches_oracle_across_calls(z, n):
     params, cubes, onehot = make_problem(z, n, 31 + z, np.float64)
     d = orc.dims(z)
