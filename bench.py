@@ -131,9 +131,10 @@ def main():
     comm = None
     if use_dist and os.environ.get("CCNN_ALLREDUCE", "oneshot") != "rccl":
         from gcn_amd.comm import NodeComm
+        os.environ.setdefault("CCNN_COMM_WAIT_MS", "5000")   # a broken exchange must fail fast, not stall the bench
         try:
             comm = NodeComm(d.nparams, torch.float32)
-            if not comm.self_test(rounds=2):
+            if not comm.self_test(rounds=2, z=z):
                 comm.close()
                 comm = None
         except Exception as e:   # raised on every rank alike (see NodeComm)
@@ -165,6 +166,19 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
+    if comm is not None:
+        # the exchange passed its self-test; had it stalled during warm-up anyway, finish on RCCL
+        st_all = [None] * world
+        dist.all_gather_object(st_all, comm.status())
+        if any(st_all):
+            if rank == 0:
+                print("one-shot exchange timed out during warm-up; using RCCL", file=sys.stderr)
+            comm.close()
+            comm = None
+            params.copy_(torch.from_numpy(params_h).to(dev))
+            for i in range(args.warmup):
+                step(i)
+            fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)

@@ -434,6 +434,7 @@ double run(const Options &opt, const Variant &v, const matio::Array &scene_a, co
             CK(hipSetDevice(dev[k].id));
             CK(hipDeviceSynchronize());
         }
+        for (auto c : xch) ccnn_comm_disconnect(c);
         for (auto c : xch) ccnn_comm_destroy(c);
         CK(hipSetDevice(dev[0].id));
     } else if (nd > 1) {

@@ -53,6 +53,8 @@ class NodeComm:
         if getattr(self, "_h", None):
             torch.cuda.synchronize(self.device)
             dist.barrier(group=self.group)   # nobody unmaps while a peer's kernel may still write
+            _l.load().ccnn_comm_disconnect(self._h)
+            dist.barrier(group=self.group)   # nobody recycles its buffer while a peer still maps it
             self._destroy()
 
     def status(self):
@@ -78,9 +80,54 @@ class NodeComm:
             _l.check(lib.ccnn_allreduce_update_f64(self._h, _ptr(params), _ptr(grad), float(lr), int(divisor),
                                                    params.numel(), _stream()), "ccnn_allreduce_update_f64")
 
-    def self_test(self, n=None, rounds=4):
+    def _agree(self, ok):
+        flagged = [None] * self.world
+        dist.all_gather_object(flagged, bool(ok), group=self.group)   # all ranks take the same branch
+        return all(flagged)
+
+    def _self_test_step(self, z, B=8):
+        """One minibatch step with the exchange inside its reduction kernel against gradient +
+        the group's all_reduce + update, from the same parameters and per-rank samples."""
+        from . import ops
+        import numpy as np
+        d = _l.dims(z)
+        npdt = np.float32 if self.dtype == torch.float32 else np.float64
+        rng = np.random.default_rng(77)                      # same parameters on every rank
+        p0 = torch.from_numpy(((rng.random(d.nparams) - 0.5) / 10).astype(npdt)).to(self.device)
+        rng = np.random.default_rng(78 + self.rank)          # different samples
+        cubes = torch.from_numpy(rng.random((B, d.cube)).astype(npdt)).to(self.device)
+        oh = np.zeros((B, 13), dtype=np.int32)
+        oh[np.arange(B), rng.integers(0, 13, B)] = 1
+        oh = torch.from_numpy(oh).to(self.device)
+        lr = 0.04
+        p_dp, p_ref = p0.clone(), p0.clone()
+        ops.mbgd_step(p_dp, cubes, oh, 0, B, z, lr, comm=self, divisor=B * self.world)
+        torch.cuda.synchronize(self.device)
+        if not self._agree(self.status() == 0):
+            return False
+        g, _ = ops.mbgd_grad(p_ref, cubes, oh, 0, B, z)
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_reduce(g, group=self.group)
+        else:
+            h = g.cpu()
+            dist.all_reduce(h, group=self.group)
+            g.copy_(h)
+        ops.update(p_ref, g, lr, z, divisor=B * self.world)
+        torch.cuda.synchronize(self.device)
+        tol = 1e-5 if self.dtype == torch.float32 else 1e-12     # the two sums differ in order only
+        err = float((p_dp - p_ref).abs().max()) / float(p_ref.abs().max())
+        if err > tol:
+            import sys
+            print(f"[rank {self.rank}] in-step exchange self-test: relative error {err:.3e} > {tol:.0e}", file=sys.stderr)
+        return self._agree(err <= tol)
+
+    def self_test(self, n=None, rounds=4, z=None):
         """True iff the one-shot exchange reproduces the group's all_reduce on random data, on
-        every rank.  Any failure (mismatch, time-out) means: do not use it."""
+        every rank, and (with z) the minibatch step that exchanges inside its reduction kernel
+        reproduces gradient + all_reduce + update.  Any failure (mismatch, time-out) means: do
+        not use it."""
+        if z is not None and not self._self_test_step(z):
+            return False
         n = self.max_elems if n is None else n
         on_device = dist.get_backend(self.group) == "nccl"   # gloo reduces host tensors
         g = torch.Generator(device="cpu").manual_seed(1234 + self.rank)
@@ -92,8 +139,10 @@ class NodeComm:
             self.all_reduce(a)
             torch.cuda.synchronize(self.device)
             ok = bool(torch.equal(a.to(ref.device), ref)) and self.status() == 0
-            flagged = [None] * self.world
-            dist.all_gather_object(flagged, ok, group=self.group)   # all ranks leave the loop together
-            if not all(flagged):
+            if not ok:
+                import sys
+                bad = int((a.to(ref.device) != ref).sum())
+                print(f"[rank {self.rank}] all-reduce self-test round {k}: {bad} of {n} elements differ, status {self.status()}", file=sys.stderr)
+            if not self._agree(ok):
                 return False   # a failing call may have cost a whole wait limit: do not repeat it
         return True

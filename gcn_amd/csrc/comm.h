@@ -25,7 +25,7 @@ struct CommDev {            // passed to kernels by value; world == 0 means "no 
     char *peer[COMM_MAX_RANKS];   // every rank's exchange buffer as mapped here ([rank] = the local one)
     int world, rank;
     long slot_bytes;              // bytes of one [parity][rank] slot
-    long flags_off, status_off;   // byte offsets inside a buffer
+    long flags_off, status_off;   // byte offsets inside a buffer (the word after status holds the rank's nonce)
     int nflags;
     unsigned long long spin_ticks;   // how long a workgroup waits for a peer (100 MHz ticks)
 };
@@ -109,10 +109,10 @@ __device__ __forceinline__ bool comm_load_tagged(const unsigned long long *src, 
 
 // After a workgroup has written its part into slot [par][rank] of every peer: make the writes
 // visible system-wide, then raise flag [par][rank][part] at every peer.  All threads call it.
-// The fence is required: with only a wait for the stores' acknowledgements a flag was observed
-// to overtake its payload (4 ranks, fp64).  It writes back the whole L2, so it is cheap in a
-// kernel that follows small ones and costs >10 us right behind a kernel that left megabytes of
-// dirty lines; kernels in that position use the flag-in-word transfer below instead.
+// The fence is what the memory model offers for "payload before flag" (a wait for the stores'
+// acknowledgements alone is not a documented guarantee).  It writes back the whole L2, so it is
+// cheap in a kernel that follows small ones and costs >10 us right behind a kernel that left
+// megabytes of dirty lines; kernels in that position use the flag-in-word transfer instead.
 __device__ __forceinline__ void comm_publish(const CommDev &c, int par, unsigned step, int part, int tid)
 {
     __threadfence_system();
@@ -158,10 +158,16 @@ struct ccnn_comm {
     int device;
     long max_elems;
     int elem;
-    size_t total_bytes;
+    size_t total_bytes;   // bytes of the layout
+    size_t alloc_bytes;   // bytes of the allocation behind it (a pooled buffer may be larger)
     bool opened[ccnn::COMM_MAX_RANKS];
     unsigned step;
-    // sequence number and parity of the next call (all ranks issue the same calls in the same order)
+    unsigned nonce;   // drawn at creation; the ranks' nonces together seed the sequence numbers
+    // Sequence number and parity of the next call (all ranks issue the same calls in the same
+    // order).  Numbering starts at a value derived from every rank's nonce, so the numbers of one
+    // set of buffers are not those of the previous set: exchange buffers are recycled within a
+    // process, and a leftover word that carried a number that is expected again would be taken
+    // for current if the clearing of the recycled buffer were ever reordered after a peer's store.
     unsigned next_step()
     {
         step++;

@@ -17,8 +17,13 @@
 // which each peer did after its kernel of call k (the last reader of that parity) had finished.
 // The buffers are uncached (fine-grained) device memory: peers' writes bypass the local L2,
 // so must the local reads.
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <new>
+#include <random>
+#include <vector>
 
 #include "comm.h"
 #include "profile.h"
@@ -114,6 +119,22 @@ int allreduce_launch(ccnn_comm *cm, T *target, const T *src, long n, Rule rule, 
 
 using namespace ccnn;
 
+namespace {
+// Exchange buffers are never handed back to the runtime while the process lives: on this
+// stack, once a buffer that peers had mapped is unmapped there AND freed here, the next set of
+// buffers misbehaves (peers' writes land in unrelated allocations of this process: observed as
+// corrupted inputs of the first step after re-creating the buffers, 100 % reproducible with 4
+// ranks).  Keeping the allocation avoids it, so destroyed buffers wait here for the next create.
+struct PooledBuffer {
+    void *ptr;
+    size_t bytes;
+    int device;
+};
+std::mutex g_pool_mu;
+std::vector<PooledBuffer> g_pool;
+
+}  // namespace
+
 extern "C" {
 
 int ccnn_comm_create(int world, int rank, long max_elems, int elem_size, ccnn_comm_t **comm, void *handle)
@@ -150,13 +171,34 @@ int ccnn_comm_create(int world, int rank, long max_elems, int elem_size, ccnn_co
     }
     hipError_t e = hipGetDevice(&cm->device);
     void *buf = nullptr;
+    cm->alloc_bytes = cm->total_bytes;
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (size_t i = 0; i < g_pool.size(); i++) {
+            if (g_pool[i].device == cm->device && g_pool[i].bytes >= cm->total_bytes) {
+                buf = g_pool[i].ptr;
+                cm->alloc_bytes = g_pool[i].bytes;
+                g_pool.erase(g_pool.begin() + i);
+                break;
+            }
+        }
+    }
     // uncached: peers write it over xGMI behind the local L2's back
-    if (e == hipSuccess) e = hipExtMallocWithFlags(&buf, cm->total_bytes, hipDeviceMallocUncached);
+    if (e == hipSuccess && !buf) e = hipExtMallocWithFlags(&buf, cm->total_bytes, hipDeviceMallocUncached);
     if (e == hipSuccess) e = hipMemset(buf, 0, cm->total_bytes);
     if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) {
+        std::random_device rd;
+        cm->nonce = rd() ^ (unsigned)std::chrono::steady_clock::now().time_since_epoch().count() ^
+                    (unsigned)(reinterpret_cast<uintptr_t>(cm) >> 4);
+        e = hipMemcpy(static_cast<char *>(buf) + d.status_off + 8, &cm->nonce, sizeof(unsigned), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t *>(handle), buf);
     if (e != hipSuccess) {
-        if (buf) (void)hipFree(buf);
+        if (buf) {
+            std::lock_guard<std::mutex> lk(g_pool_mu);
+            g_pool.push_back({buf, cm->alloc_bytes, cm->device});
+        }
         delete cm;
         return (int)e;
     }
@@ -177,6 +219,16 @@ int ccnn_comm_connect(ccnn_comm_t *cm, const void *handles)
         cm->dev.peer[r] = static_cast<char *>(p);
         cm->opened[r] = true;
     }
+    // every rank wrote its nonce before it published its handle: combine them into the first
+    // sequence number (the same on every rank)
+    unsigned seed = 0;
+    for (int r = 0; r < cm->dev.world; r++) {
+        unsigned v = 0;
+        hipError_t e = hipMemcpy(&v, cm->dev.peer[r] + cm->dev.status_off + 8, sizeof(v), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return (int)e;
+        seed = seed * 2654435761u + v;
+    }
+    cm->step = seed | 1u;
     return 0;
 }
 
@@ -195,6 +247,9 @@ int ccnn_comm_connect_local(ccnn_comm_t *cm, ccnn_comm_t *const *peers)
         }
         cm->dev.peer[r] = peers[r]->dev.peer[r];
     }
+    unsigned seed = 0;
+    for (int r = 0; r < cm->dev.world; r++) seed = seed * 2654435761u + (r == cm->dev.rank ? cm->nonce : peers[r]->nonce);
+    cm->step = seed | 1u;
     return 0;
 }
 
@@ -208,12 +263,26 @@ int ccnn_comm_status(ccnn_comm_t *cm, int *status)
     return 0;
 }
 
+int ccnn_comm_disconnect(ccnn_comm_t *cm)
+{
+    if (!cm) return CCNN_E_INVALID;
+    for (int r = 0; r < cm->dev.world; r++) {
+        if (r == cm->dev.rank) continue;
+        if (cm->opened[r]) (void)hipIpcCloseMemHandle(cm->dev.peer[r]);
+        cm->opened[r] = false;
+        cm->dev.peer[r] = nullptr;
+    }
+    return 0;
+}
+
 int ccnn_comm_destroy(ccnn_comm_t *cm)
 {
     if (!cm) return 0;
-    for (int r = 0; r < cm->dev.world; r++)
-        if (cm->opened[r]) (void)hipIpcCloseMemHandle(cm->dev.peer[r]);
-    if (cm->dev.peer[cm->dev.rank]) (void)hipFree(cm->dev.peer[cm->dev.rank]);
+    (void)ccnn_comm_disconnect(cm);
+    if (cm->dev.peer[cm->dev.rank]) {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        g_pool.push_back({cm->dev.peer[cm->dev.rank], cm->alloc_bytes, cm->device});
+    }
     delete cm;
     return 0;
 }

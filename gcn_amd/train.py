@@ -140,7 +140,7 @@ def fit_mbgd(params, cubes, onehot, z, batch=100, lr=None, min_err=None, max_ite
         from .comm import NodeComm
         try:
             node = NodeComm(params.numel(), params.dtype, group=group)
-            if not node.self_test(rounds=2):
+            if not node.self_test(rounds=2, z=z):
                 node.close()
                 node = None
         except Exception:   # raised on every rank alike (see NodeComm)

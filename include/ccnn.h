@@ -255,6 +255,11 @@ int ccnn_comm_create(int world, int rank, long max_elems, int elem_size, ccnn_co
 int ccnn_comm_connect(ccnn_comm_t *comm, const void *handles);
 int ccnn_comm_connect_local(ccnn_comm_t *comm, ccnn_comm_t *const *peers);
 int ccnn_comm_status(ccnn_comm_t *comm, int *status);
+/* Tear-down is two-phase across ranks: every rank first unmaps its peers' buffers
+ * (ccnn_comm_disconnect), and only when ALL ranks have done so may any rank free its own
+ * (ccnn_comm_destroy; it disconnects first if that was not done).  The buffer itself goes to a
+ * process-wide pool for the next ccnn_comm_create instead of back to the runtime. */
+int ccnn_comm_disconnect(ccnn_comm_t *comm);
 int ccnn_comm_destroy(ccnn_comm_t *comm);
 /* buf[k] = sum over ranks of buf[k], in place. */
 int ccnn_allreduce_f32(ccnn_comm_t *comm, float *buf, long n, void *stream);

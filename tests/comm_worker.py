@@ -2,7 +2,6 @@
 cuda:0 (the test box has one GPU); the rendezvous and the reference all-reduce use gloo."""
 import os
 import sys
-import time
 
 import numpy as np
 import torch
@@ -60,17 +59,20 @@ def main():
         return
     z = 103
     d = L.dims(z)
-    for dtype in (torch.float32, torch.float64):
+    # fp64 first: the fp32 set then reuses the fp64 set's (larger) pooled buffer, so both a fresh
+    # and a recycled exchange buffer are covered; a third set checks a second recycling
+    for dtype in (torch.float64, torch.float32, torch.float64):
         comm = NodeComm(d.nparams, dtype)
-        print(f"[rank {rank}] {dtype} connected", file=sys.stderr, flush=True)
-        t0 = time.perf_counter()
         a = torch.ones(8, dtype=dtype, device=dev)
         comm.all_reduce(a)
         torch.cuda.synchronize()
-        print(f"[rank {rank}] first all_reduce {time.perf_counter() - t0:.3f}s -> {a[0].item()} status {comm.status()}",
-              file=sys.stderr, flush=True)
         assert comm.status() == 0, "a rank gave up waiting for its peers"
-        assert comm.self_test(), "one-shot all-reduce disagrees with the group's all_reduce"
+        assert float(a[0]) == world
+        # the product's own acceptance tests, the in-step exchange first (it is the first thing a
+        # training run does with fresh buffers) and at two batch sizes
+        assert comm._self_test_step(z), "first in-step exchange on fresh buffers"
+        assert comm._self_test_step(z, B=12)
+        assert comm.self_test(z=z)
         # short vector (one partial chunk) and repeated calls (slot parity, sequence numbers)
         for n in (1, 5, 1023, 1025):
             for k in range(3):
