@@ -163,31 +163,52 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(n, first=0):
+        fence()
+        t = time.perf_counter()
+        for i in range(n):
+            step(first + i)
+        fence()
+        t = time.perf_counter() - t
+        if world > 1:
+            tt = torch.tensor([t], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t = tt.item()
+        return t
+
     for i in range(args.warmup):
         step(i)
     fence()
+    calibration = None
     if comm is not None:
-        # the exchange passed its self-test; had it stalled during warm-up anyway, finish on RCCL
+        # The exchange passed its self-test.  Had it stalled during warm-up anyway, finish on RCCL;
+        # otherwise let the rest of the warm-up decide which of the two routes this node runs
+        # faster (untimed steps of the same work; every rank sees the same max-over-ranks times).
         st_all = [None] * world
         dist.all_gather_object(st_all, comm.status())
-        if any(st_all):
-            if rank == 0:
-                print("one-shot exchange timed out during warm-up; using RCCL", file=sys.stderr)
+        keep = not any(st_all)
+        if not keep and rank == 0:
+            print("one-shot exchange timed out during warm-up; using RCCL", file=sys.stderr)
+        if keep and os.environ.get("CCNN_ALLREDUCE", "") != "oneshot":
+            ncal = max(args.warmup, 50)
+            t_one = timed(ncal)
+            held, comm = comm, None
+            for i in range(20):
+                step(i)
+            t_rccl = timed(ncal)
+            comm = held
+            calibration = {"steps": ncal, "oneshot_us_per_step": round(t_one / ncal * 1e6, 2),
+                           "rccl_us_per_step": round(t_rccl / ncal * 1e6, 2)}
+            keep = t_one <= t_rccl
+        if not keep:
             comm.close()
             comm = None
+        if calibration is not None or not keep:
             params.copy_(torch.from_numpy(params_h).to(dev))
             for i in range(args.warmup):
                 step(i)
             fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+    dt = timed(args.steps, args.warmup)
     train_pps = world * B * args.steps / dt
     assert torch.isfinite(params).all(), "training diverged"
     replicas_identical = True
@@ -350,7 +371,7 @@ def main():
                        "global_batch": B * world, "train_pixels": T, "parallelism": f"dp{world}",
                        "exchange": ("none" if not use_dist else "xgmi one-shot exchange inside the reduction kernel"
                                     if comm is not None else "rccl all-reduce + update"),
-                       "replicas_identical": replicas_identical},
+                       "exchange_calibration": calibration, "replicas_identical": replicas_identical},
             "infer_pixels_per_s": round(infer_pps, 1),
             "infer_from_scene_pixels_per_s": round(infer_scene_pps, 1),
             "infer_full_scene_pixels_per_s": round(infer_full_pps, 1),
