@@ -44,7 +44,19 @@ constexpr int LDP = 79;     // pool tile      [16 b][79]
 constexpr int KSTEPS0 = (K + 3) / 4;   // 43 k-steps cover the 171 taps
 
 __host__ __device__ inline int conv_mtiles(int re) { return (re + 15) >> 4; }
-__host__ __device__ inline int conv_cube_pad(int re) { return WSTEP * 16 * conv_mtiles(re) + 160; }
+// zero-padded cube length: the windows of a padded 16-position tile end at 288 mt + 156, the
+// shifted-filter tile below reads up to 18 (re - 1) + 227
+__host__ __device__ inline int conv_cube_pad(int re) { return WSTEP * 16 * conv_mtiles(re) + 224; }
+
+// Packed tile for the four filters that do not fill a second 16-wide MFMA tile.  Column 4 g + f'
+// holds filter 16 + f' shifted down by 18 g taps (zeros elsewhere), so against a row that starts
+// at cube offset 72 j the product yields filter 16 + f' at position 4 j + g: one MFMA chain of 57
+// k-steps covers 64 positions x 4 filters, where a plain filter tile spends 4 x 43 k-steps with
+// 12 of its 16 columns empty.
+constexpr int WX_TAPS = 228;                    // 171 + 3 x 18 = 225 taps, whole k-steps
+constexpr int KSTEPSX = WX_TAPS / 4;
+constexpr int WP_LEN = WL_TILE + WX_TAPS * LDWK;   // filters 0..15 tap-major, then the packed tile
+
 
 // Cooperative global -> LDS staging with U loads in flight per thread: all loads of
 // a round are issued before the first LDS store waits on them (a plain
@@ -303,6 +315,123 @@ __device__ __forceinline__ void conv_pool_tiles(const T *cube, int cube_stride, 
         auto put1 = [&](int f, int m, T v, int bt) { put(sidx, f, m, v, bt); };
         pool_tile(acc0, bias0, col, true, tile * 16, re, lane, put1);
         pool_tile(acc1, bias1, 16 + col, 16 + col < F, tile * 16, re, lane, put1);
+    }
+}
+
+// One MFMA chain of KS k-steps as two interleaved accumulators (even / odd k-steps).  The
+// operands of the next four k-steps are fetched before the MFMAs of the current four are
+// issued, so a wave always has LDS reads in flight behind its matrix instructions.
+// ap walks A along k (stride 1), bp walks B (stride LDWK).
+template <typename T, int KS>
+__device__ __forceinline__ typename Mma<T>::acc_t mma_chain(const T *ap, const T *bp)
+{
+    constexpr int NB4 = (KS + 3) / 4;   // batches of up to four k-steps
+    typename Mma<T>::acc_t acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+    T a[2][4], b[2][4];
+    auto load = [&](int bi, int set) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (4 * bi + u < KS) {
+                a[set][u] = ap[4 * (4 * bi + u)];
+                b[set][u] = bp[4 * (4 * bi + u) * LDWK];
+            }
+        }
+    };
+    load(0, 0);
+#pragma unroll
+    for (int bi = 0; bi < NB4; bi++) {
+        const int set = bi & 1;
+        if (bi + 1 < NB4) load(bi + 1, set ^ 1);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (4 * bi + u < KS) {
+                if (u & 1) acc2 = Mma<T>::mma(a[set][u], b[set][u], acc2);
+                else acc = Mma<T>::mma(a[set][u], b[set][u], acc);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) acc[r] += acc2[r];
+    return acc;
+}
+
+// Orders this wave's LDS traffic: everything its lanes wrote before is visible to all its
+// lanes after (the LDS serves one wave's requests in order; this keeps the compiler from
+// moving accesses across and waits for outstanding ones).  No other wave is involved.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Conv forward + tanh + pool of ONE LDS-resident sample by ONE wave: ceil(re/16) chains of 43
+// k-steps for filters 0..15 (rows = 16 positions) and ceil(ceil(re/4)/16) chains of 57 k-steps
+// for filters 16..19 on the packed tile (rows = 16 consecutive j; columns = 4 shifts x 4
+// filters, so both members of a pool pair sit in one row, 4 columns apart).
+// wl = [172][LDWK] filters 0..15 | [228][LDWK] packed tile; cube zero-padded to
+// conv_cube_pad(re).  put(f, m, value, winning position).
+template <typename T, typename Put>
+__device__ __forceinline__ void conv_pool_wave(const T *cube, const T *wl, int re, T bias0, T biasx, int lane,
+                                               Put put)
+{
+    const int col = lane & 15, kq = lane >> 4;
+    const int mt = conv_mtiles(re);
+    const int jmax = (re - 1) >> 2;
+    const T *bp0 = wl + kq * LDWK + col;
+    for (int tile = 0; tile < mt; tile++) {
+        const T *ap = cube + WSTEP * (tile * 16 + col) + kq;
+        const typename Mma<T>::acc_t acc = mma_chain<T, KSTEPS0>(ap, bp0);
+        pool_tile(acc, bias0, col, true, tile * 16, re, lane, put);
+    }
+    const int g = col >> 2, fl = col & 3;
+    for (int tau = 0; 16 * tau <= jmax; tau++) {
+        const int j = min(tau * 16 + col, jmax);   // clamped: rows past the end are discarded below
+        const T *ap = cube + 4 * WSTEP * j + kq;
+        const typename Mma<T>::acc_t acc = mma_chain<T, KSTEPSX>(ap, bp0 + WL_TILE);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int t = 4 * (tau * 16 + Mma<T>::row(lane, r)) + g;
+            const T v = act(acc[r] + biasx);
+            const T vn = __shfl_xor(v, 4);           // same row, shift g ^ 1: the pool partner
+            if (!(g & 1) && t < re) {
+                T best = v;
+                int bt = t;
+                if (t + 1 < re && best < vn) {       // strict '<': the first maximum wins
+                    best = vn;
+                    bt = t + 1;
+                }
+                put(16 + fl, t >> 1, best, bt);
+            }
+        }
+    }
+}
+
+// Stages the 20 x 171 filters as conv_pool_wave wants them (zero taps and columns included), by a
+// workgroup of nt threads; FLIP as in stage_filters.  Needs a barrier after.
+template <typename T, bool FLIP>
+__device__ __forceinline__ void stage_filters_packed(const T *__restrict__ w0, T *wl, int tid, int nt)
+{
+    for (int e = tid; e < WP_LEN; e += nt) wl[e] = 0;
+    __syncthreads();
+    for (int base = 0; base < F * K; base += 8 * nt) {
+        T tmp[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) tmp[u] = w0[min(base + u * nt + tid, F * K - 1)];   // clamped, unconditional
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int e = base + u * nt + tid;
+            if (e < F * K) {
+                const int f = e / K, k = e - f * K;
+                const int kk = FLIP ? K - 1 - k : k;
+                if (f < 16) {
+                    wl[kk * LDWK + f] = tmp[u];
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; g++) wl[WL_TILE + (kk + WSTEP * g) * LDWK + 4 * g + (f - 16)] = tmp[u];
+                }
+            }
+        }
     }
 }
 

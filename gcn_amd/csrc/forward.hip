@@ -9,6 +9,7 @@
 //                                 output layer, softmax and device argmax) + count_correct_kernel
 //   update_params_row/col      -> update_*_kernel (after an all-reduce; single-GPU training
 //                                 fuses the update into grad_reduce, see mbgd.hip)
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -33,131 +34,151 @@ int raise_smem_limit(const void *fn, size_t bytes)
 }
 
 // ---------------------------------------------------------------------------
-// convolution + tanh + max-pool.  A workgroup takes SPI (2 or 4) samples per
-// iteration (grid-stride over such groups; the filters are staged once): the
-// SPI x ceil(re/16) position tiles are dealt round-robin to the 4 waves so every
-// wave has the same number of MFMA chains, and the next group's cubes are loaded
-// into registers while the current group's MFMAs run.
+// convolution + tanh + max-pool.  Every WAVE owns whole samples: it keeps its current sample's
+// cube and pooled features in a private LDS region, runs that sample's MFMA chains
+// (conv_pool_wave), and holds the next sample's cube in registers meanwhile.  The waves of a
+// workgroup share only the staged filters, so after the prologue there is no workgroup barrier:
+// the waves drift apart and one wave's loads, activations and stores run under the others'
+// matrix instructions.  (With 4 samples per 256-thread workgroup and two barriers per group the
+// matrix pipes idled during everything that was not an MFMA: 297 us per 65536 Pavia samples,
+// 125 us of it with the MFMAs removed.)
 // pool[row][f*mre + m] = pooled value.
-constexpr int CONV_MAXREG = 32;   // cube elements a thread may hold in flight for the next group
-
-// NREG (8, 16, 24 or 32) >= ceil(SPI*cube_len/256) is a template parameter so that the
-// prefetch is straight-line code: loads under a run-time guard are waited for at the
-// guard's join, which would put the whole memory latency back in front of the MFMAs.
+//
+// NREG >= ceil(cube_len/64) is a template parameter so that the prefetch is straight-line code:
+// loads under a run-time guard are waited for at the guard's join, which would put the whole
+// memory latency back in front of the MFMAs.
 //
 // SCENE: the samples are not pre-gathered cubes but pixels of the scene: `cubes` is the scene
 // [z][plane], idx9 the neighbour lists, and element b*9+j of a sample's cube is read straight
 // from scene[idx9[sample][j] + b*plane] (preprocessing, gcn_mbgd_fp64.cu:599-615, folded into
-// the load), so full-scene inference never materialises 9z values per pixel in HBM.  The
-// neighbour lists of a group sit in LDS one iteration ahead of the loads that use them.
-template <typename T, bool FLIP, int SPI, int NREG, bool SCENE>
-__global__ __launch_bounds__(256) void conv_pool_fwd(const T *__restrict__ params,
-                                                     const T *__restrict__ cubes, long first, int nrows,
-                                                     int cube_len, int re, int mre, int off_b0,
-                                                     T *__restrict__ pool, const int *__restrict__ idx9,
-                                                     long plane)
+// the load), so full-scene inference never materialises 9z values per pixel in HBM.  A wave's
+// neighbour lists sit in LDS one sample ahead of the loads that use them.
+constexpr int CONV_MAXREG = 64;    // cube elements a lane may hold in flight for the next sample
+constexpr int CONV_MAXWAVES = 8;   // waves per workgroup (fewer when the per-wave LDS region is large)
+
+template <typename T, bool FLIP, int NREG, bool SCENE>
+__global__ __launch_bounds__(64 * CONV_MAXWAVES) void conv_pool_fwd(const T *__restrict__ params,
+                                                                     const T *__restrict__ cubes, long first,
+                                                                     long nrows, int cube_len, int re, int mre,
+                                                                     int off_b0, T *__restrict__ pool,
+                                                                     const int *__restrict__ idx9, long plane)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ int sidx[2][SPI * NB];   // SCENE: neighbour lists of the group being loaded / the one after
-    constexpr int RPS = NREG / SPI;                 // prefetch registers per sample
-    const int cube_pad = conv_cube_pad(re);
-    T *cube = reinterpret_cast<T *>(smem);          // [SPI][cube_pad]
-    T *wl = cube + SPI * cube_pad;
-    T *pl = wl + WL_LEN;                          // [SPI][pout] pooled values of the group
+    __shared__ int sidx_all[CONV_MAXWAVES][2][16];   // SCENE: lists of the sample being loaded / the one after
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nwv = blockDim.x >> 6;
     const int col = lane & 15;
     const int pout = F * mre;
-    const long ngroups = ((long)nrows + SPI - 1) / SPI;
+    const int cube_pad = conv_cube_pad(re);
+    T *wl = reinterpret_cast<T *>(smem);
+    T *cube = wl + WP_LEN + wave * (cube_pad + pout);   // this wave's sample
+    T *pl = cube + cube_pad;                            // and its pooled features
+    int(*sidx)[16] = sidx_all[wave];
 
-    for (int e = tid; e < SPI * cube_pad; e += 256) cube[e] = 0;   // pads stay zero: loads only touch [0, cube_len)
-    stage_filters<T, FLIP>(params, wl, tid);
+    stage_filters_packed<T, FLIP>(params, wl, tid, blockDim.x);
+    for (int e = lane; e < cube_pad; e += 64) cube[e] = 0;   // pads stay zero: loads only touch [0, cube_len)
     const T bias0 = params[off_b0 + col];
-    const T bias1 = params[off_b0 + min(16 + col, F - 1)];
+    const T biasx = params[off_b0 + 16 + (col & 3)];
+    __syncthreads();   // the only workgroup barrier: filters staged
 
-    T creg[NREG];
-    auto issue = [&](long g, int ib) {   // next group's cubes -> registers (clamped, unconditional)
+    const long stride = (long)gridDim.x * nwv;
+    long row = (long)blockIdx.x * nwv + wave;
+    if (row >= nrows) return;
+
+    // The next cube waits in registers while this one's chains run, when that many registers
+    // are to spare (beyond it the compiler spills them to scratch: then it is loaded after the
+    // chains and only the other waves hide its latency).
+    constexpr bool PREFETCH = NREG * sizeof(T) <= 48 * 4;
+    T creg[PREFETCH ? NREG : 1];
+    auto issue = [&](long r, int ib) {   // sample r's cube -> registers (clamped, unconditional)
+        if (SCENE) {
 #pragma unroll
-        for (int si = 0; si < SPI; si++) {
-            if (SCENE) {
-#pragma unroll
-                for (int u = 0; u < RPS; u++) {
-                    const int e = min(u * 256 + tid, cube_len - 1);
-                    const int b = e / NB, j = e - b * NB;
-                    creg[si * RPS + u] = cubes[sidx[ib][si * NB + j] + b * plane];
-                }
-            } else {
-                const long r = g * SPI + si < nrows ? g * SPI + si : (long)nrows - 1;
-                const T *src = cubes + (first + r) * (long)cube_len;
-#pragma unroll
-                for (int u = 0; u < RPS; u++) creg[si * RPS + u] = src[min(u * 256 + tid, cube_len - 1)];
+            for (int u = 0; u < NREG; u++) {
+                const int e = min(u * 64 + lane, cube_len - 1);
+                const int b = e / NB, j = e - b * NB;
+                creg[u] = cubes[sidx[ib][j] + b * plane];
             }
+        } else {
+            const T *src = cubes + (first + r) * (long)cube_len;
+#pragma unroll
+            for (int u = 0; u < NREG; u++) creg[u] = src[min(u * 64 + lane, cube_len - 1)];
         }
     };
-    auto load_idx = [&](long g) {   // one neighbour index of group g per thread (clamped, unconditional)
-        const int e = min(tid, SPI * NB - 1);
-        const int si = e / NB, j = e - si * NB;
-        const long gc = g < ngroups ? g : ngroups - 1;
-        const long r = gc * SPI + si < nrows ? gc * SPI + si : (long)nrows - 1;
-        return idx9[(first + r) * NB + j];
+    auto load_idx = [&](long r) {   // one neighbour index of sample r per lane (clamped, unconditional)
+        return idx9[(first + (r < nrows ? r : nrows - 1)) * NB + min(lane, NB - 1)];
     };
     auto commit = [&]() {
 #pragma unroll
-        for (int si = 0; si < SPI; si++)
-#pragma unroll
-            for (int u = 0; u < RPS; u++) {
-                const int e = u * 256 + tid;
-                if (e < cube_len) cube[si * cube_pad + e] = creg[si * RPS + u];
-            }
+        for (int u = 0; u < NREG; u++) {
+            const int e = u * 64 + lane;
+            if (e < cube_len) cube[e] = creg[u];
+        }
     };
 
-    long g = blockIdx.x;
-    int ib = 0;   // sidx[ib] = lists of the group whose loads are issued next
+    auto fetch = [&](long r, int ib) {   // without prefetch: sample r's cube -> LDS, 16 elements per lane at a time
+#pragma unroll 1
+        for (int u0 = 0; u0 < NREG; u0 += 16) {
+            T t[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const int e = min((u0 + u) * 64 + lane, cube_len - 1);
+                if (SCENE) {
+                    const int b = e / NB, j = e - b * NB;
+                    t[u] = cubes[sidx[ib][j] + b * plane];
+                } else {
+                    t[u] = cubes[(first + r) * (long)cube_len + e];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const int e = (u0 + u) * 64 + lane;
+                if (e < cube_len) cube[e] = t[u];
+            }
+        }
+    };
+
+    int ib = 0;   // sidx[ib] = list of the sample whose loads are issued next
     if (SCENE) {
-        if (g >= ngroups) return;
-        const int i0 = load_idx(g), i1 = load_idx(g + gridDim.x);
-        if (tid < SPI * NB) {
-            sidx[0][tid] = i0;
-            sidx[1][tid] = i1;
+        const int i0 = load_idx(row), i1 = load_idx(row + stride);
+        if (lane < NB) {
+            sidx[0][lane] = i0;
+            sidx[1][lane] = i1;
         }
-        __syncthreads();
+        wave_sync();
     }
-    if (g < ngroups) issue(g, 0);
+    if (PREFETCH) {
+        issue(row, 0);
+        commit();
+    } else {
+        fetch(row, 0);
+    }
     ib = 1;
-    __syncthreads();
-    if (g < ngroups) commit();
-    for (; g < ngroups; g += gridDim.x) {
-        __syncthreads();                                   // this group's cubes are in LDS; pl is free
-        const long gn = g + gridDim.x;
-        if (gn < ngroups) issue(gn, ib);                   // next group's loads fly during the MFMAs
+    wave_sync();
+    for (; row < nrows; row += stride) {
+        const long rn = row + stride;
+        if (PREFETCH && rn < nrows) issue(rn, ib);         // next sample's loads fly during the MFMAs
         int inext = 0;
-        if (SCENE) inext = load_idx(gn + gridDim.x);       // and the lists of the group after it
-        conv_pool_tiles<T>(cube, cube_pad, SPI, wl, re, bias0, bias1, lane, wave,
-                           [&](int si, int f, int m, T v, int) { pl[si * pout + f * mre + m] = v; });
-        __syncthreads();                                   // pooled values complete, cubes no longer read
+        if (SCENE) inext = load_idx(rn + stride);          // and the list of the sample after it
+        conv_pool_wave<T>(cube, wl, re, bias0, biasx, lane, [&](int f, int m, T v, int) { pl[f * mre + m] = v; });
+        wave_sync();                                       // pooled values complete, cube no longer read
         if (SCENE) {
-            ib ^= 1;                                       // the lists issue(g) used are dead: reuse their buffer
-            if (tid < SPI * NB) sidx[ib][tid] = inext;
+            ib ^= 1;                                       // the list issue(row) used is dead: reuse its slot
+            if (lane < NB) sidx[ib][lane] = inext;
         }
-        if (gn < ngroups) commit();
-        const int ns = (int)(((long)nrows - g * SPI) < SPI ? ((long)nrows - g * SPI) : SPI);
-        T *dst = pool + (g * SPI) * pout;
-        for (int o = tid; o < ns * pout; o += 256) dst[o] = pl[o];
+        if (rn < nrows) {
+            if (PREFETCH) commit();
+            else fetch(rn, ib ^ 1);
+        }
+        T *dst = pool + row * pout;
+        for (int o = lane; o < pout; o += 64) dst[o] = pl[o];
+        wave_sync();                                       // next cube and list in place, pl free again
     }
 }
 
 template <typename T>
-size_t conv_smem(const ccnn_dims_t &d, int spi)
+size_t conv_smem(const ccnn_dims_t &d, int nwaves)
 {
-    return (size_t)(spi * conv_cube_pad(d.re) + WL_LEN + spi * d.pout) * sizeof(T);
-}
-
-// Samples per iteration: 4 when their cubes fit the per-thread prefetch registers and
-// the LDS budget leaves room for a second workgroup per CU, else 2.
-template <typename T>
-int conv_spi(const ccnn_dims_t &d)
-{
-    const bool fits4 = 4 * ((d.cube + 255) / 256) <= CONV_MAXREG && conv_smem<T>(d, 4) <= 80 * 1024;
-    return fits4 ? 4 : 2;
+    return (size_t)(WP_LEN + nwaves * (conv_cube_pad(d.re) + d.pout)) * sizeof(T);
 }
 
 // ---------------------------------------------------------------------------
@@ -373,8 +394,37 @@ __global__ void count_correct_kernel(const int *__restrict__ argmax, const int *
 // ---------------------------------------------------------------------------
 // host-side orchestration
 
-constexpr long FWD_CHUNK = 16384;  // samples per forward pass through the workspace
-constexpr int PERSIST_GRID = 1024; // workgroups for the grid-stride kernels
+// Samples per forward pass through the workspace: as many as keep the pooled features within
+// 128 MB, so that the persistent conv workgroups amortise their filter staging over many groups
+// (CCNN_FWD_CHUNK overrides it: tests use a small value to cross chunk boundaries cheaply).
+inline long fwd_chunk_rows(const ccnn_dims_t &d, size_t elem)
+{
+    if (const char *s = getenv("CCNN_FWD_CHUNK")) {
+        const long v = atol(s);
+        if (v > 0) return v;
+    }
+    long rows = (long)((128ull << 20) / ((size_t)d.pout * elem)) & ~1023L;
+    return rows < 16384 ? 16384 : rows > 131072 ? 131072 : rows;
+}
+
+// Workgroups of `fn` the device holds at once (the grid of a persistent kernel: more would run
+// as a second, mostly empty round).
+int resident_blocks(const void *fn, int threads, size_t smem)
+{
+    static std::mutex mu;
+    static std::map<std::pair<const void *, std::pair<int, size_t>>, int> known;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    std::lock_guard<std::mutex> lk(mu);
+    int &have = known[{fn, {dev, smem}}];
+    if (have > 0) return have;
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, smem) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return 0;
+    have = per_cu * cus;
+    return have;
+}
 
 template <typename T>
 struct FwdWs {
@@ -397,33 +447,43 @@ int forward_impl(const T *params, const T *cubes, long n, int z, T *probs, int *
     if (make_dims(z, &d)) return CCNN_E_INVALID;
     if (!params || !cubes || n < 0 || (n > 0 && !ws)) return CCNN_E_INVALID;
     if (n == 0) return 0;
-    const long rows = n < FWD_CHUNK ? n : FWD_CHUNK;
+    const long chunk = fwd_chunk_rows(d, sizeof(T));
+    const long rows = n < chunk ? n : chunk;
     if (ws_bytes < FwdWs<T>::bytes(rows, d)) return CCNN_E_WORKSPACE;
     FwdWs<T> w(ws, rows, d);
-    const int spi = conv_spi<T>(d);
-    const int nreg8 = (spi * ((d.cube + 255) / 256) + 7) / 8;   // prefetch registers per thread, in eights
-    if (nreg8 > CONV_MAXREG / 8) return CCNN_E_RANGE;
-    const size_t csm = conv_smem<T>(d, spi);
-    typedef void (*ConvKern)(const T *, const T *, long, int, int, int, int, int, T *, const int *, long);
-    static const ConvKern kern[2][2][4] = {
-        {{conv_pool_fwd<T, FLIP, 2, 8, false>, conv_pool_fwd<T, FLIP, 2, 16, false>,
-          conv_pool_fwd<T, FLIP, 2, 24, false>, conv_pool_fwd<T, FLIP, 2, 32, false>},
-         {conv_pool_fwd<T, FLIP, 4, 8, false>, conv_pool_fwd<T, FLIP, 4, 16, false>,
-          conv_pool_fwd<T, FLIP, 4, 24, false>, conv_pool_fwd<T, FLIP, 4, 32, false>}},
-        {{conv_pool_fwd<T, FLIP, 2, 8, true>, conv_pool_fwd<T, FLIP, 2, 16, true>,
-          conv_pool_fwd<T, FLIP, 2, 24, true>, conv_pool_fwd<T, FLIP, 2, 32, true>},
-         {conv_pool_fwd<T, FLIP, 4, 8, true>, conv_pool_fwd<T, FLIP, 4, 16, true>,
-          conv_pool_fwd<T, FLIP, 4, 24, true>, conv_pool_fwd<T, FLIP, 4, 32, true>}}};
-    const ConvKern conv = kern[idx9 != nullptr][spi == 4][nreg8 - 1];
-    if (int e = allow_smem(conv, csm)) return e;
+    const int nreg16 = ((d.cube + 63) / 64 + 15) / 16;   // prefetch registers per lane, in sixteens
+    if (nreg16 > CONV_MAXREG / 16) return CCNN_E_RANGE;
+    typedef void (*ConvKern)(const T *, const T *, long, long, int, int, int, int, T *, const int *, long);
+    static const ConvKern kern[2][4] = {
+        {conv_pool_fwd<T, FLIP, 16, false>, conv_pool_fwd<T, FLIP, 32, false>, conv_pool_fwd<T, FLIP, 48, false>,
+         conv_pool_fwd<T, FLIP, 64, false>},
+        {conv_pool_fwd<T, FLIP, 16, true>, conv_pool_fwd<T, FLIP, 32, true>, conv_pool_fwd<T, FLIP, 48, true>,
+         conv_pool_fwd<T, FLIP, 64, true>}};
+    const ConvKern conv = kern[idx9 != nullptr][nreg16 - 1];
+    // Waves per workgroup: the count (8, 4, 2 or 1) that puts the most waves on the device; LDS
+    // (the filter image plus a cube and a pooled row per wave) and registers both limit it.
+    int nwv = 0, resident = 0;
+    size_t csm = 0;
+    for (int w = CONV_MAXWAVES; w >= 1; w >>= 1) {
+        const size_t b = conv_smem<T>(d, w);
+        if (b > 160 * 1024) continue;
+        if (int e = allow_smem(conv, b)) return e;
+        const int r = resident_blocks(reinterpret_cast<const void *>(conv), 64 * w, b);
+        if (r * w > resident * nwv) {
+            nwv = w;
+            resident = r;
+            csm = b;
+        }
+    }
+    if (nwv == 0) return CCNN_E_RANGE;
     if (int e = allow_smem(fc_head_fwd<T>, FcHeadLds<T>::bytes)) return e;
     for (long s0 = 0; s0 < n; s0 += rows) {
         const int nr = (int)((n - s0) < rows ? (n - s0) : rows);
-        const int groups = (nr + spi - 1) / spi;
-        const int pg = groups < PERSIST_GRID ? groups : PERSIST_GRID;
+        const int groups = (nr + nwv - 1) / nwv;
+        const int pg = groups < resident ? groups : resident;
         {
-            launch("conv_pool_fwd", conv, dim3(pg), dim3(256), csm, st, params, cubes, s0, nr, d.cube, d.re, d.mre,
-                   d.off_b0, w.pool, idx9, plane);
+            launch("conv_pool_fwd", conv, dim3(pg), dim3(64 * nwv), csm, st, params, cubes, s0, (long)nr, d.cube, d.re,
+                   d.mre, d.off_b0, w.pool, idx9, plane);
         }
         CCNN_LAUNCH_CHECK();
         {
@@ -446,7 +506,8 @@ size_t ccnn_forward_workspace_bytes(long n, int z, int elem_size)
 {
     ccnn_dims_t d;
     if (make_dims(z, &d) || n <= 0) return 0;
-    const long rows = n < FWD_CHUNK ? n : FWD_CHUNK;
+    const long chunk = fwd_chunk_rows(d, elem_size == 8 ? 8 : 4);
+    const long rows = n < chunk ? n : chunk;
     return elem_size == 8 ? FwdWs<double>::bytes(rows, d) : FwdWs<float>::bytes(rows, d);
 }
 

@@ -2,6 +2,8 @@
 fixtures.  Tolerances: gather / labels / indices bit-exact; fp64 weights, losses
 and probabilities 1e-12 relative to the tensor's largest magnitude; fp32 1e-5.
 argmax must agree wherever the oracle's top-2 margin exceeds the tolerance."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -140,7 +142,11 @@ def test_forward_chunked_large_batch():
     z, n = 103, 20000
     params, cubes, _ = make_problem(z, 64, 9, np.float32)
     big = np.tile(cubes, (n // 64 + 1, 1))[:n]
-    probs, am = ops.forward(dev(params), dev(big), z)
+    os.environ["CCNN_FWD_CHUNK"] = "16384"   # the default chunk holds far more than 20000 samples
+    try:
+        probs, am = ops.forward(dev(params), dev(big), z)
+    finally:
+        del os.environ["CCNN_FWD_CHUNK"]
     p64, a64 = ops.forward(dev(params), dev(cubes), z)
     assert torch.equal(probs.view(-1)[:64 * 13], p64.view(-1))
     assert torch.equal(probs[-(n % 64):], p64[:n % 64])
