@@ -53,19 +53,42 @@ int raise_smem_limit(const void *fn, size_t bytes)
 // from scene[idx9[sample][j] + b*plane] (preprocessing, gcn_mbgd_fp64.cu:599-615, folded into
 // the load), so full-scene inference never materialises 9z values per pixel in HBM.  A wave's
 // neighbour lists sit in LDS one sample ahead of the loads that use them.
+// Diagnostic builds only (-DCCNN_CONV_CLOCK): workgroup 7, wave 0 stamps the shader clock and the
+// 100 MHz wall clock around its sample loop; ccnn_debug_conv_clock() returns the four stamps.
+#ifdef CCNN_CONV_CLOCK
+__device__ unsigned long long g_conv_clock[4];
+__device__ unsigned long long g_conv_wg[3 * 2048];   // per workgroup: entry, loop start, loop end (100 MHz)
+#define CONV_STAMP(k)                                                                 \
+    do {                                                                              \
+        if (blockIdx.x == 7 && threadIdx.x == 0) {                                    \
+            g_conv_clock[2 * (k)] = __builtin_amdgcn_s_memtime();                     \
+            g_conv_clock[2 * (k) + 1] = __builtin_amdgcn_s_memrealtime();             \
+        }                                                                             \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048)                             \
+            atomicMax(&g_conv_wg[3 * blockIdx.x + 1 + (k)], (unsigned long long)__builtin_amdgcn_s_memrealtime()); \
+    } while (0)
+#else
+#define CONV_STAMP(k) do { } while (0)
+#endif
+
 constexpr int CONV_MAXREG = 64;    // cube elements a lane may hold in flight for the next sample
 constexpr int CONV_MAXWAVES = 8;   // waves per workgroup (fewer when the per-wave LDS region is large)
+constexpr int CONV_CTR_STRIDE = 32;   // ints between two work counters (one 128-byte line each)
 
 template <typename T, bool FLIP, int NREG, bool SCENE>
 __global__ __launch_bounds__(64 * CONV_MAXWAVES) void conv_pool_fwd(const T *__restrict__ params,
                                                                      const T *__restrict__ cubes, long first,
                                                                      long nrows, int cube_len, int re, int mre,
                                                                      int off_b0, T *__restrict__ pool,
-                                                                     const int *__restrict__ idx9, long plane)
+                                                                     const int *__restrict__ idx9, long plane,
+                                                                     int *__restrict__ ctr)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int sidx_all[CONV_MAXWAVES][2][16];   // SCENE: lists of the sample being loaded / the one after
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef CCNN_CONV_CLOCK
+    if (tid == 0 && blockIdx.x < 2048) g_conv_wg[3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
     const int nwv = blockDim.x >> 6;
     const int col = lane & 15;
     const int pout = F * mre;
@@ -81,9 +104,24 @@ __global__ __launch_bounds__(64 * CONV_MAXWAVES) void conv_pool_fwd(const T *__r
     const T biasx = params[off_b0 + 16 + (col & 3)];
     __syncthreads();   // the only workgroup barrier: filters staged
 
-    const long stride = (long)gridDim.x * nwv;
-    long row = (long)blockIdx.x * nwv + wave;
-    if (row >= nrows) return;
+    // Work distribution.  Rows [0, 3W) (W = waves of the grid) are fixed: wave g owns g, W + g and
+    // 2W + g, which fills its pipeline (current cube in LDS, next in registers, the one after
+    // known) without waiting for anybody.  The rest is handed out one row at a time, because waves
+    // do not run equally fast (measured: loop times of 185..234 us for equal shares): eight
+    // counters, one per eighth of the remaining rows, workgroup b using counter b % 8 (the
+    // workgroups of one XCD share one counter), two grabs ahead of the row being computed.
+    const long W = (long)gridDim.x * nwv;
+    const long gw = (long)blockIdx.x * nwv + wave;
+    if (gw >= nrows) return;
+    const int xcd = blockIdx.x & 7;
+    const long rem = nrows > 3 * W ? nrows - 3 * W : 0;
+    const long per = (rem + 7) / 8;
+    const long xlo = 3 * W + xcd * per;
+    const long xhi = xlo + per < nrows ? xlo + per : nrows;
+    int *my_ctr = ctr + CONV_CTR_STRIDE * xcd;
+    long row = gw;
+    long r_nxt = W + gw < nrows ? W + gw : -1;
+    long r_nn = 2 * W + gw < nrows ? 2 * W + gw : -1;
 
     // The next cube waits in registers while this one's chains run, when that many registers
     // are to spare (beyond it the compiler spills them to scratch: then it is loaded after the
@@ -105,7 +143,7 @@ __global__ __launch_bounds__(64 * CONV_MAXWAVES) void conv_pool_fwd(const T *__r
         }
     };
     auto load_idx = [&](long r) {   // one neighbour index of sample r per lane (clamped, unconditional)
-        return idx9[(first + (r < nrows ? r : nrows - 1)) * NB + min(lane, NB - 1)];
+        return idx9[(first + (r >= 0 ? r : 0)) * NB + min(lane, NB - 1)];
     };
     auto commit = [&]() {
 #pragma unroll
@@ -139,7 +177,7 @@ __global__ __launch_bounds__(64 * CONV_MAXWAVES) void conv_pool_fwd(const T *__r
 
     int ib = 0;   // sidx[ib] = list of the sample whose loads are issued next
     if (SCENE) {
-        const int i0 = load_idx(row), i1 = load_idx(row + stride);
+        const int i0 = load_idx(row), i1 = load_idx(r_nxt);
         if (lane < NB) {
             sidx[0][lane] = i0;
             sidx[1][lane] = i1;
@@ -154,25 +192,43 @@ __global__ __launch_bounds__(64 * CONV_MAXWAVES) void conv_pool_fwd(const T *__r
     }
     ib = 1;
     wave_sync();
-    for (; row < nrows; row += stride) {
-        const long rn = row + stride;
-        if (PREFETCH && rn < nrows) issue(rn, ib);         // next sample's loads fly during the MFMAs
+    CONV_STAMP(0);
+    while (row >= 0) {
+        const bool want = rem > 0 && r_nn >= 0;            // wave-uniform: rows are left to hand out
+        int got = 0;
+        if (want && lane == 0) got = atomicAdd(my_ctr, 1);
+        if (PREFETCH && r_nxt >= 0) issue(r_nxt, ib);      // next sample's loads fly during the MFMAs
         int inext = 0;
-        if (SCENE) inext = load_idx(rn + stride);          // and the list of the sample after it
+        if (SCENE) inext = load_idx(r_nn);                 // and the list of the sample after it
         conv_pool_wave<T>(cube, wl, re, bias0, biasx, lane, [&](int f, int m, T v, int) { pl[f * mre + m] = v; });
         wave_sync();                                       // pooled values complete, cube no longer read
         if (SCENE) {
-            ib ^= 1;                                       // the list issue(row) used is dead: reuse its slot
+            ib ^= 1;                                       // the list issue(r_nxt) used is dead: reuse its slot
             if (lane < NB) sidx[ib][lane] = inext;
         }
-        if (rn < nrows) {
+        if (r_nxt >= 0) {
             if (PREFETCH) commit();
-            else fetch(rn, ib ^ 1);
+            else fetch(r_nxt, ib ^ 1);
         }
         T *dst = pool + row * pout;
-        for (int o = lane; o < pout; o += 64) dst[o] = pl[o];
+        {
+            typedef typename Vec16<T>::type V;
+            constexpr int VW = Vec16<T>::W;
+            const V *src = reinterpret_cast<const V *>(pl);
+            V *dv = reinterpret_cast<V *>(dst);
+            for (int o = lane; o < pout / VW; o += 64) dv[o] = src[o];   // pout = 20 mre: whole 16-byte vectors
+        }
         wave_sync();                                       // next cube and list in place, pl free again
+        long r_new = -1;
+        if (want) {
+            const long r = xlo + __builtin_amdgcn_readfirstlane(got);
+            r_new = r < xhi ? r : -1;
+        }
+        row = r_nxt;
+        r_nxt = r_nn;
+        r_nn = r_new;
     }
+    CONV_STAMP(1);
 }
 
 template <typename T>
@@ -429,11 +485,16 @@ int resident_blocks(const void *fn, int threads, size_t smem)
 template <typename T>
 struct FwdWs {
     T *pool;
-    static size_t bytes(long rows, const ccnn_dims_t &d) { return align_up((size_t)rows * d.pout * sizeof(T)); }
+    int *ctr;   // work counters of conv_pool_fwd
+    static size_t bytes(long rows, const ccnn_dims_t &d)
+    {
+        return align_up((size_t)rows * d.pout * sizeof(T)) + align_up(8 * CONV_CTR_STRIDE * sizeof(int));
+    }
     FwdWs(void *ws, long rows, const ccnn_dims_t &d)
     {
         Carver c(ws);
         pool = c.take<T>((size_t)rows * d.pout);
+        ctr = c.take<int>(8 * CONV_CTR_STRIDE);
     }
 };
 
@@ -453,7 +514,7 @@ int forward_impl(const T *params, const T *cubes, long n, int z, T *probs, int *
     FwdWs<T> w(ws, rows, d);
     const int nreg16 = ((d.cube + 63) / 64 + 15) / 16;   // prefetch registers per lane, in sixteens
     if (nreg16 > CONV_MAXREG / 16) return CCNN_E_RANGE;
-    typedef void (*ConvKern)(const T *, const T *, long, long, int, int, int, int, T *, const int *, long);
+    typedef void (*ConvKern)(const T *, const T *, long, long, int, int, int, int, T *, const int *, long, int *);
     static const ConvKern kern[2][4] = {
         {conv_pool_fwd<T, FLIP, 16, false>, conv_pool_fwd<T, FLIP, 32, false>, conv_pool_fwd<T, FLIP, 48, false>,
          conv_pool_fwd<T, FLIP, 64, false>},
@@ -481,9 +542,13 @@ int forward_impl(const T *params, const T *cubes, long n, int z, T *probs, int *
         const int nr = (int)((n - s0) < rows ? (n - s0) : rows);
         const int groups = (nr + nwv - 1) / nwv;
         const int pg = groups < resident ? groups : resident;
+        if ((long)nr > 3L * pg * nwv) {   // rows beyond the fixed shares are handed out through the counters
+            hipError_t e = hipMemsetAsync(w.ctr, 0, 8 * CONV_CTR_STRIDE * sizeof(int), st);
+            if (e != hipSuccess) return (int)e;
+        }
         {
             launch("conv_pool_fwd", conv, dim3(pg), dim3(64 * nwv), csm, st, params, cubes, s0, (long)nr, d.cube, d.re,
-                   d.mre, d.off_b0, w.pool, idx9, plane);
+                   d.mre, d.off_b0, w.pool, idx9, plane, w.ctr);
         }
         CCNN_LAUNCH_CHECK();
         {
@@ -499,6 +564,17 @@ int forward_impl(const T *params, const T *cubes, long n, int z, T *probs, int *
 }  // namespace ccnn
 
 using namespace ccnn;
+
+#ifdef CCNN_CONV_CLOCK
+extern "C" int ccnn_debug_conv_clock(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_clock), sizeof(unsigned long long) * 4);
+}
+extern "C" int ccnn_debug_conv_wg(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_wg), sizeof(unsigned long long) * 3 * 2048);
+}
+#endif
 
 extern "C" {
 

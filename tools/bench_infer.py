@@ -19,3 +19,32 @@ torch.cuda.synchronize(); t0 = time.perf_counter(); reps = 20
 for _ in range(reps): ops.forward(params, cubes, z, want_probs=False, workspace=ws)
 torch.cuda.synchronize(); t = (time.perf_counter() - t0) / reps
 print(f"z={z} n={n} {np.dtype(dt).name}: {t*1e3:.3f} ms  {n/t/1e6:.1f} M pixels/s")
+if os.environ.get("CCNN_CONV_CLOCK"):
+    import ctypes as C
+    lib = C.CDLL(os.environ["CCNN_LIB_PATH"])
+    t = (C.c_ulonglong * 4)()
+    for _ in range(200): ops.forward(params, cubes, z, want_probs=False, workspace=ws)   # let the clock settle under load
+    torch.cuda.synchronize()
+    assert lib.ccnn_debug_conv_clock(t) == 0
+    print(f"sustained back-to-back launches: in-kernel clock {(t[2] - t[0]) / ((t[3] - t[1]) * 10):.3f} GHz, loop {(t[3] - t[1]) / 100:.1f} us")
+    from gcn_amd import lib as L
+    L.profile_enable(True)
+    for _ in range(20): ops.forward(params, cubes, z, want_probs=False, workspace=ws)
+    torch.cuda.synchronize()
+    L.profile_enable(False)
+    print({k: round(ms / cnt * 1e3, 1) for k, (ms, cnt) in L.profile_report().items()}, "us per launch (dispatch events)")
+    assert lib.ccnn_debug_conv_clock(t) == 0
+    cyc, ticks = t[2] - t[0], t[3] - t[1]
+    print(f"conv loop of one wave: {cyc} shader cycles in {ticks * 10} ns -> {cyc / (ticks * 10):.3f} GHz")
+    w = (C.c_ulonglong * (3 * 2048))()
+    assert lib.ccnn_debug_conv_wg(w) == 0
+    a = np.array(w[:], dtype=np.int64).reshape(2048, 3)
+    a = a[a[:, 0] > 0]
+    t0 = a[:, 0].min()
+    us = (a - t0) / 100.0
+    print(f"{len(a)} workgroups; entry: min {us[:,0].min():.1f} median {np.median(us[:,0]):.1f} max {us[:,0].max():.1f} us; "
+          f"loop start: median {np.median(us[:,1]):.1f} max {us[:,1].max():.1f}; loop end: min {us[:,2].min():.1f} "
+          f"median {np.median(us[:,2]):.1f} max {us[:,2].max():.1f}")
+    late = us[us[:, 0] > 20]
+    print(f"workgroups entering later than 20 us: {len(late)}; their loop time median {np.median(late[:,2]-late[:,1]) if len(late) else 0:.1f} us; "
+          f"early ones' loop time median {np.median((us[:,2]-us[:,1])[us[:,0] <= 20]):.1f} us")
