@@ -263,6 +263,20 @@ struct FcHeadLds {
     static constexpr size_t bytes = (size_t)total * sizeof(T);
 };
 
+#ifdef CCNN_CONV_CLOCK
+__device__ unsigned long long g_fc_wg[4 * 4096];   // per workgroup: entry, K loop start, K loop end, exit (100 MHz)
+#define FC_STAMP(k)                                                                                  \
+    do {                                                                                             \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) g_fc_wg[4 * blockIdx.x + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+extern "C" int ccnn_debug_fc_wg(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fc_wg), sizeof(unsigned long long) * 4 * 4096);
+}
+#else
+#define FC_STAMP(k) do { } while (0)
+#endif
+
 template <typename T>
 __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params, int off_w1, int off_b1,
                                                    int off_w2, int off_b2, const T *__restrict__ pool,
@@ -282,12 +296,8 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
     const int nb = min(FH_MS, nrows - r0);
     const T *W1 = params + off_w1;
     const int nch = (pout + PCHUNK - 1) / PCHUNK;
+    FC_STAMP(0);
 
-    stage<6, 256>(params + off_w2, H * O, tid, [&](int e, T v) { w2s[e] = v; });
-    if (tid < H) b1s[tid] = params[off_b1 + tid];
-    if (tid < O) b2s[tid] = params[off_b2 + tid];
-    // neuron columns 100..111 of the W1 image are never loaded: keep them zero
-    for (int e = tid; e < PCHUNK * (LDW1 - H); e += 256) wl[(e / (LDW1 - H)) * LDW1 + H + e % (LDW1 - H)] = 0;
 
     const int mtile = wave & 1;
     const int nt0 = (wave >> 1) ? 4 : 0;
@@ -335,9 +345,15 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
         }
     };
 
-    issue(0);
+    issue(0);   // first: the chunk's loads fly while the small operands below are staged
+    stage<6, 256>(params + off_w2, H * O, tid, [&](int e, T v) { w2s[e] = v; });
+    if (tid < H) b1s[tid] = params[off_b1 + tid];
+    if (tid < O) b2s[tid] = params[off_b2 + tid];
+    // neuron columns 100..111 of the W1 image are never loaded: keep them zero
+    for (int e = tid; e < PCHUNK * (LDW1 - H); e += 256) wl[(e / (LDW1 - H)) * LDW1 + H + e % (LDW1 - H)] = 0;
     __syncthreads();
     commit(0);
+    FC_STAMP(1);
     for (int c = 0; c < nch; c++) {
         __syncthreads();                     // chunk c is in LDS
         if (c + 1 < nch) issue(c + 1);       // next chunk's loads fly during the MFMAs
@@ -358,6 +374,7 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
         if (c + 1 < nch) commit(c + 1);
     }
 
+    FC_STAMP(2);
     // ---- epilogue: z1 -> LDS, then 8 lanes per sample --------------------------------
     T *z1s = wl;
 #pragma unroll
@@ -371,7 +388,7 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
     __syncthreads();
     const int s = tid >> 3, j8 = tid & 7;
     T *zr = z1s + s * LDZ;
-    for (int n = j8; n < H; n += 8) zr[n] = 2 / (1 + 1 / rexp((zr[n] + b1s[n]) * 2)) - 1;   // gcn_mbgd_fp64.cu:302
+    for (int n = j8; n < H; n += 8) zr[n] = act(zr[n] + b1s[n]);   // gcn_mbgd_fp64.cu:302
     __syncthreads();
     const int o0 = j8, o1 = j8 + 8;          // lane j8 produces outputs j8 and j8+8 (the latter for j8 < 5)
     const bool has1 = o1 < O;
@@ -405,6 +422,7 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
             }
         argmax[r0 + s] = idx;
     }
+    FC_STAMP(3);
 }
 
 // ---------------------------------------------------------------------------

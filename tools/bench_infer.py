@@ -48,3 +48,13 @@ if os.environ.get("CCNN_CONV_CLOCK"):
     late = us[us[:, 0] > 20]
     print(f"workgroups entering later than 20 us: {len(late)}; their loop time median {np.median(late[:,2]-late[:,1]) if len(late) else 0:.1f} us; "
           f"early ones' loop time median {np.median((us[:,2]-us[:,1])[us[:,0] <= 20]):.1f} us")
+    w = (C.c_ulonglong * (4 * 4096))()
+    assert lib.ccnn_debug_fc_wg(w) == 0
+    a = np.array(w[:], dtype=np.int64).reshape(4096, 4)
+    a = a[a[:, 0] > 0]
+    us = (a - a[:, 0].min()) / 100.0
+    d = np.diff(us, axis=1)
+    print(f"fc_head: {len(a)} workgroups; entry median {np.median(us[:,0]):.1f} max {us[:,0].max():.1f}; exit max {us[:,3].max():.1f} us; "
+          f"per workgroup: prologue {np.median(d[:,0]):.1f}, K loop {np.median(d[:,1]):.1f}, epilogue {np.median(d[:,2]):.1f} us (medians)")
+    order = np.sort(us[:, 0])
+    print("entry times (us) at 10 % steps:", [round(float(order[int(q * (len(order) - 1))]), 1) for q in np.linspace(0, 1, 11)])
