@@ -33,10 +33,11 @@ __device__ unsigned long long g_fb_ticks[32];
 #define FB_TICK(k) do { } while (0)
 #endif
 
-#ifndef CCNN_FB_WKEEP
-#define CCNN_FB_WKEEP 0   // rounds of W1 rows sample_fwd_bwd keeps in registers between its two walks
-                          // (measured: 0, 1 and 2 rounds take the same time, 4 spill; the walks are not
-                          // bound by their loads)
+#ifndef CCNN_FB_UFF
+#define CCNN_FB_UFF 16   // W1 rows (16-byte vectors) a thread keeps in flight in the forward walk
+#endif
+#ifndef CCNN_FB_UFB
+#define CCNN_FB_UFB 1    // rounds of 16 W1 rows in flight in the backward walk
 #endif
 #ifndef CCNN_STOP_PHASE
 #define CCNN_STOP_PHASE 0   // diagnostic builds only: end sample_fwd_bwd after phase N
@@ -251,11 +252,8 @@ __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ param
     // Every workgroup reads all of W1; start each at a different row so that at any moment
     // the 128 workgroups pull from different L2 channels instead of queueing on the same lines.
     const int rot = (int)((row * 37) % pout);
-    constexpr int UF = 16;   // W1 rows in flight per thread
-    // The backward walk below visits W1 with the same (row, column) -> thread assignment, so the
-    // rows of the first WKEEP rounds can stay in registers and only the rest is read a second time.
-    constexpr int WKEEP = CCNN_FB_WKEEP;
-    V wkeep[WKEEP > 0 ? WKEEP : 1][UF];
+    constexpr int UF = 16;    // W1 rows per reduce-scatter round of the backward walk
+    constexpr int UFF = CCNN_FB_UFF;   // W1 rows in flight per thread in the forward walk
     auto w1_rows = [&](int pb, V(&w)[UF]) {
 #pragma unroll
         for (int u = 0; u < UF; u++) {
@@ -266,26 +264,21 @@ __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ param
     };
     {
         V acc = {};
-        auto fma_rows = [&](int pb, const V(&w)[UF]) {
+        for (int pb = 0; pb < pout; pb += G * UFF) {
+            V w[UFF];
 #pragma unroll
-            for (int u = 0; u < UF; u++) {
+            for (int u = 0; u < UFF; u++) {
+                int p = min(pb + u * G + g, pout - 1) + rot;
+                p = p >= pout ? p - pout : p;
+                w[u] = W1v[(long)p * NQ + qc];
+            }
+#pragma unroll
+            for (int u = 0; u < UFF; u++) {
                 int p = min(pb + u * G + g, pout - 1) + rot;
                 p = p >= pout ? p - pout : p;
                 const T x = (qv && pb + u * G + g < pout) ? pl[p] : T(0);
                 acc += w[u] * x;
             }
-        };
-#pragma unroll
-        for (int it = 0; it < WKEEP; it++) {
-            if (it * G * UF < pout) {
-                w1_rows(it * G * UF, wkeep[it]);
-                fma_rows(it * G * UF, wkeep[it]);
-            }
-        }
-        for (int pb = WKEEP * G * UF; pb < pout; pb += G * UF) {
-            V w[UF];
-            w1_rows(pb, w);
-            fma_rows(pb, w);
         }
         if (qv) reinterpret_cast<V *>(z1p + g * H)[q] = acc;
     }
@@ -380,13 +373,12 @@ __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ param
                 delta[(f >> 4) * L.ldd + px[p] * LDWK + (f & 15)] = dv;
             }
         };
+        for (int pb = 0; pb < pout; pb += CCNN_FB_UFB * G * UF) {
+            V w[CCNN_FB_UFB][UF];   // rows of several rounds in flight before the first is reduced
 #pragma unroll
-        for (int it = 0; it < WKEEP; it++)
-            if (it * G * UF < pout) dpool_rows(it * G * UF, wkeep[it]);
-        for (int pb = WKEEP * G * UF; pb < pout; pb += G * UF) {
-            V w[UF];
-            w1_rows(pb, w);
-            dpool_rows(pb, w);
+            for (int h = 0; h < CCNN_FB_UFB; h++) w1_rows(pb + h * G * UF, w[h]);
+#pragma unroll
+            for (int h = 0; h < CCNN_FB_UFB; h++) dpool_rows(pb + h * G * UF, w[h]);
         }
     }
     __syncthreads();
@@ -503,16 +495,21 @@ __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int o
             const T *bp = d1 + min(n0 + col, H - 1);
             typename Mma<T>::acc_t acc = {0, 0, 0, 0};
             const int ks = (B + 3) >> 2;
-            for (int s = 0; s < ks; s += 16) {   // sixteen k-steps of operands in flight
-                T a[16], w[16];
+            // k-steps of operands in flight: fp32 takes a batch of 128 in one memory round trip
+            // (16 -> 32: step 24.6 -> 23.3 us).  fp64 stays at 16 so that the kernel keeps within 128
+            // registers and two workgroups fit a CU: ranks that share one GPU (the multi-process
+            // tests) wait for each other inside this kernel, so all of them must be resident at once.
+            constexpr int KF = sizeof(T) == 4 ? 32 : 16;
+            for (int s = 0; s < ks; s += KF) {
+                T a[KF], w[KF];
 #pragma unroll
-                for (int u = 0; u < 16; u++) {
+                for (int u = 0; u < KF; u++) {
                     const int b = min(4 * (s + u) + kq, B - 1);
                     a[u] = ap[(long)b * pout];
                     w[u] = bp[(long)b * H];
                 }
 #pragma unroll
-                for (int u = 0; u < 16; u++) {
+                for (int u = 0; u < KF; u++) {
                     const bool bv = 4 * (s + u) + kq < B;
                     acc = Mma<T>::mma((bv && pv) ? a[u] : T(0), (bv && nv) ? w[u] : T(0), acc);
                 }
