@@ -122,6 +122,32 @@ def test_forward_scene_equals_gather_then_forward(dtype, z):
     assert relerr(p2.cpu().numpy(), p_ref) < (1e-5 if dtype == np.float32 else 1e-12)
 
 
+@pytest.mark.parametrize("dtype,z", [(np.float32, 103), (np.float64, 40), (np.float32, 230)])
+def test_forward_long_lists_every_row_once(dtype, z):
+    """Lists much longer than the conv kernel's fixed shares (three rows per resident wave): the
+    rows beyond them are handed out through work counters.  Every pixel of a scene, repeated, from
+    the scene and from cubes; both must agree bit for bit with the same pixels classified in
+    short lists (which never touch the counters)."""
+    x, y = 64, 50
+    scene, labels = synth.small_scene(x, y, z, 11, dtype)
+    labels[:] = 1                                         # every pixel is a sample
+    di = prep.scan_labels(labels, x, y)
+    tr9, te9, _, _ = prep.build_index(labels, di, x, y)
+    idx = np.concatenate([tr9.reshape(-1, 9), te9.reshape(-1, 9)])
+    idx = np.ascontiguousarray(np.tile(idx, (12, 1)))     # 38400 rows
+    orc.srand(4)
+    params = dev(orc.init_params_f32(z) if dtype == np.float32 else orc.init_params_f64(z, 0))
+    sc, idx_d = dev(scene), dev(idx)
+    p_scene, a_scene = ops.forward_scene(params, sc, idx_d, x, y, z)
+    p_cubes, a_cubes = ops.forward(params, ops.gather(sc, idx_d, x, y, z), z)
+    assert torch.equal(p_scene, p_cubes) and torch.equal(a_scene, a_cubes)
+    n1 = x * y
+    for s0 in range(0, n1, 800):                          # short lists: fixed shares only
+        p_short, _ = ops.forward_scene(params, sc, idx_d[s0:s0 + 800].contiguous(), x, y, z)
+        for rep in (0, 5, 11):
+            assert torch.equal(p_scene[rep * n1 + s0:rep * n1 + s0 + 800], p_short)
+
+
 @pytest.mark.parametrize("dtype,z,n", [(np.float64, 176, 67), (np.float32, 200, 130), (np.float32, 103, 33),
                                        (np.float64, 21, 5), (np.float32, 224, 17), (np.float64, 22, 3),
                                        (np.float32, 448, 9), (np.float64, 448, 5), (np.float32, 60, 1)])
