@@ -98,12 +98,6 @@ __global__ __launch_bounds__(64 * CONV_MAXWAVES) void conv_pool_fwd(const T *__r
     T *pl = cube + cube_pad;                            // and its pooled features
     int(*sidx)[16] = sidx_all[wave];
 
-    stage_filters_packed<T, FLIP>(params, wl, tid, blockDim.x);
-    for (int e = lane; e < cube_pad; e += 64) cube[e] = 0;   // pads stay zero: loads only touch [0, cube_len)
-    const T bias0 = params[off_b0 + col];
-    const T biasx = params[off_b0 + 16 + (col & 3)];
-    __syncthreads();   // the only workgroup barrier: filters staged
-
     // Work distribution.  Rows [0, 3W) (W = waves of the grid) are fixed: wave g owns g, W + g and
     // 2W + g, which fills its pipeline (current cube in LDS, next in registers, the one after
     // known) without waiting for anybody.  The rest is handed out one row at a time, because waves
@@ -112,7 +106,7 @@ __global__ __launch_bounds__(64 * CONV_MAXWAVES) void conv_pool_fwd(const T *__r
     // workgroups of one XCD share one counter), two grabs ahead of the row being computed.
     const long W = (long)gridDim.x * nwv;
     const long gw = (long)blockIdx.x * nwv + wave;
-    if (gw >= nrows) return;
+    const bool active = gw < nrows;   // (every wave helps to stage the filters first)
     const int xcd = blockIdx.x & 7;
     const long rem = nrows > 3 * W ? nrows - 3 * W : 0;
     const long per = (rem + 7) / 8;
@@ -175,8 +169,10 @@ __global__ __launch_bounds__(64 * CONV_MAXWAVES) void conv_pool_fwd(const T *__r
         }
     };
 
+    // Prologue: the first cube's loads are issued before the filters are staged, so the two
+    // memory round trips overlap.
     int ib = 0;   // sidx[ib] = list of the sample whose loads are issued next
-    if (SCENE) {
+    if (SCENE && active) {
         const int i0 = load_idx(row), i1 = load_idx(r_nxt);
         if (lane < NB) {
             sidx[0][lane] = i0;
@@ -184,12 +180,15 @@ __global__ __launch_bounds__(64 * CONV_MAXWAVES) void conv_pool_fwd(const T *__r
         }
         wave_sync();
     }
-    if (PREFETCH) {
-        issue(row, 0);
-        commit();
-    } else {
-        fetch(row, 0);
-    }
+    if (PREFETCH && active) issue(row, 0);
+    stage_filters_packed<T, FLIP>(params, wl, tid, blockDim.x);
+    for (int e = lane; e < cube_pad; e += 64) cube[e] = 0;   // pads stay zero: loads only touch [0, cube_len)
+    const T bias0 = params[off_b0 + col];
+    const T biasx = params[off_b0 + 16 + (col & 3)];
+    __syncthreads();   // the only workgroup barrier: filters staged
+    if (!active) return;
+    if (PREFETCH) commit();
+    else fetch(row, 0);
     ib = 1;
     wave_sync();
     CONV_STAMP(0);
