@@ -408,7 +408,8 @@ __device__ __forceinline__ void conv_pool_wave(const T *cube, const T *wl, int r
 }
 
 // Stages the 20 x 171 filters as conv_pool_wave wants them (zero taps and columns included), by a
-// workgroup of nt threads; FLIP as in stage_filters.  Needs a barrier after.
+// workgroup of nt threads.  The fp32 reference walks the filter backwards in the forward pass only
+// (gcn_mbgd_fp32.cu:241-243): FLIP stores tap k at 170-k.  Needs a barrier after.
 template <typename T, bool FLIP>
 __device__ __forceinline__ void stage_filters_packed(const T *__restrict__ w0, T *wl, int tid, int nt)
 {
@@ -433,20 +434,6 @@ __device__ __forceinline__ void stage_filters_packed(const T *__restrict__ w0, T
             }
         }
     }
-}
-
-// Stages the 20 x 171 filters into the two wl[172][LDWK] tiles (zero taps/filters included).  The
-// fp32 reference walks the filter backwards in the forward pass only
-// (gcn_mbgd_fp32.cu:241-243): FLIP stores tap k at 170-k.  Needs a barrier after.
-template <typename T, bool FLIP>
-__device__ __forceinline__ void stage_filters(const T *__restrict__ w0, T *wl, int tid)
-{
-    for (int e = tid; e < WL_LEN; e += 256) wl[e] = 0;
-    __syncthreads();
-    stage<7, 256>(w0, F * K, tid, [&](int e, T v) {
-        const int f = e / K, k = e - f * K;
-        wl[wl_index(f, FLIP ? K - 1 - k : k)] = v;
-    });
 }
 
 }  // namespace ccnn
