@@ -280,9 +280,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params, int off_w1, int off_b1,
                                                    int off_w2, int off_b2, const T *__restrict__ pool,
                                                    int nrows, int pout, T *__restrict__ probs,
-                                                   int *__restrict__ argmax)
+                                                   int *__restrict__ argmax, int *__restrict__ ctr)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int s_next;   // the workgroup's next tile, grabbed one tile ahead
     typedef FcHeadLds<T> L;
     typedef typename Vec16<T>::type V;
     constexpr int VW = Vec16<T>::W;
@@ -291,20 +292,28 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
     T *es = base + L::es, *ps = base + L::ps;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15, kq = lane >> 4;
-    const int r0 = blockIdx.x * FH_MS;
-    const int nb = min(FH_MS, nrows - r0);
+    // Tiles of 32 samples: workgroup b starts with tile b; the tiles beyond the grid are handed
+    // out through eight counters (workgroup b uses counter b % 8, one eighth of the remaining
+    // tiles each), so the grid can be exactly what the device holds and nobody idles through a
+    // partly filled last round.
+    const int ntiles = (nrows + FH_MS - 1) / FH_MS;
+    const int xcd = blockIdx.x & 7;
+    const int rem = ntiles > (int)gridDim.x ? ntiles - (int)gridDim.x : 0;
+    const int per = (rem + 7) / 8;
+    const int xlo = (int)gridDim.x + xcd * per;
+    const int xhi = min(xlo + per, ntiles);
+    int tile = blockIdx.x;
+    int r0 = tile * FH_MS;
+    int nb = min(FH_MS, nrows - r0);
     const T *W1 = params + off_w1;
     const int nch = (pout + PCHUNK - 1) / PCHUNK;
     FC_STAMP(0);
-
 
     const int mtile = wave & 1;
     const int nt0 = (wave >> 1) ? 4 : 0;
     const T *ap = pt + (mtile * 16 + col) * LDP + kq;
     const T *bp = wl + kq * LDW1 + nt0 * 16 + col;
     typename Mma<T>::acc_t acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) acc[j] = typename Mma<T>::acc_t{0, 0, 0, 0};
 
     constexpr int NWV = (PCHUNK * H / VW + 255) / 256;      // W1 vectors per thread per chunk
     constexpr int NPT = FH_MS * PCHUNK / 256;               // pool elements per thread per chunk
@@ -348,7 +357,19 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
     stage<6, 256>(params + off_w2, H * O, tid, [&](int e, T v) { w2s[e] = v; });
     if (tid < H) b1s[tid] = params[off_b1 + tid];
     if (tid < O) b2s[tid] = params[off_b2 + tid];
-    // neuron columns 100..111 of the W1 image are never loaded: keep them zero
+  for (;;) {   // one tile per iteration; the first chunk of this tile is in wreg / preg
+    if (tid == 0) {
+        int nx = -1;
+        if (rem > 0) {
+            nx = xlo + atomicAdd(ctr + CONV_CTR_STRIDE * xcd + CONV_CTR_STRIDE / 2, 1);
+            if (nx >= xhi) nx = -1;
+        }
+        s_next = nx;   // read after the K loop's barriers
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[j] = typename Mma<T>::acc_t{0, 0, 0, 0};
+    // neuron columns 100..111 of the W1 image are never loaded: keep them zero (the previous
+    // tile's epilogue used the region)
     for (int e = tid; e < PCHUNK * (LDW1 - H); e += 256) wl[(e / (LDW1 - H)) * LDW1 + H + e % (LDW1 - H)] = 0;
     __syncthreads();
     commit(0);
@@ -375,6 +396,13 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
 
     FC_STAMP(2);
     // ---- epilogue: z1 -> LDS, then 8 lanes per sample --------------------------------
+    const int tile_next = s_next;
+    const int r0_done = r0, nb_done = nb;
+    if (tile_next >= 0) {   // the next tile's first chunk flies during this tile's epilogue
+        r0 = tile_next * FH_MS;
+        nb = min(FH_MS, nrows - r0);
+        issue(0);
+    }
     T *z1s = wl;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -405,12 +433,12 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
     const T p0 = e0 / sum, p1 = e1 / sum;
     ps[s * 16 + o0] = p0;
     if (has1) ps[s * 16 + o1] = p1;
-    if (s < nb && probs) {
-        probs[(long)(r0 + s) * O + o0] = p0;
-        if (has1) probs[(long)(r0 + s) * O + o1] = p1;
+    if (s < nb_done && probs) {
+        probs[(long)(r0_done + s) * O + o0] = p0;
+        if (has1) probs[(long)(r0_done + s) * O + o1] = p1;
     }
     __syncthreads();
-    if (argmax && j8 == 0 && s < nb) {
+    if (argmax && j8 == 0 && s < nb_done) {
         // count_err: running max starts at 0, strict '>' (gcn_mbgd_fp64.cu:636-647)
         T mx = 0;
         int idx = 0;
@@ -419,9 +447,13 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
                 mx = ps[s * 16 + i];
                 idx = i;
             }
-        argmax[r0 + s] = idx;
+        argmax[r0_done + s] = idx;
     }
     FC_STAMP(3);
+    if (tile_next < 0) break;
+    tile = tile_next;
+    __syncthreads();   // everyone is done with z1s / es / ps (and has read s_next)
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -555,11 +587,15 @@ int forward_impl(const T *params, const T *cubes, long n, int z, T *probs, int *
     }
     if (nwv == 0) return CCNN_E_RANGE;
     if (int e = allow_smem(fc_head_fwd<T>, FcHeadLds<T>::bytes)) return e;
+    const int fc_resident = resident_blocks(reinterpret_cast<const void *>(fc_head_fwd<T>), 256, FcHeadLds<T>::bytes);
+    if (fc_resident <= 0) return CCNN_E_RANGE;
     for (long s0 = 0; s0 < n; s0 += rows) {
         const int nr = (int)((n - s0) < rows ? (n - s0) : rows);
         const int groups = (nr + nwv - 1) / nwv;
         const int pg = groups < resident ? groups : resident;
-        if ((long)nr > 3L * pg * nwv) {   // rows beyond the fixed shares are handed out through the counters
+        const int ntiles = (nr + FH_MS - 1) / FH_MS;
+        const int fg = ntiles < fc_resident ? ntiles : fc_resident;
+        if ((long)nr > 3L * pg * nwv || ntiles > fg) {   // work beyond the fixed shares is handed out through the counters
             hipError_t e = hipMemsetAsync(w.ctr, 0, 8 * CONV_CTR_STRIDE * sizeof(int), st);
             if (e != hipSuccess) return (int)e;
         }
@@ -569,9 +605,9 @@ int forward_impl(const T *params, const T *cubes, long n, int z, T *probs, int *
         }
         CCNN_LAUNCH_CHECK();
         {
-            launch("fc_head_fwd", fc_head_fwd<T>, dim3((nr + FH_MS - 1) / FH_MS), dim3(256), FcHeadLds<T>::bytes, st,
+            launch("fc_head_fwd", fc_head_fwd<T>, dim3(fg), dim3(256), FcHeadLds<T>::bytes, st,
                    params, d.off_w1, d.off_b1, d.off_w2, d.off_b2, w.pool, nr, d.pout,
-                   probs ? probs + s0 * O : nullptr, argmax ? argmax + s0 : nullptr);
+                   probs ? probs + s0 * O : nullptr, argmax ? argmax + s0 : nullptr, w.ctr);
         }
         CCNN_LAUNCH_CHECK();
     }
