@@ -1,4 +1,5 @@
-"""Times ccnn_mbgd_step for one library build (diagnostic; pick the build with CCNN_LIB_PATH)."""
+"""Times ccnn_mbgd_step for one library build (diagnostic; pick the build with CCNN_LIB_PATH).
+usage: phase_probe.py [z] [B] [f32|f64]"""
 import sys, os, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -6,12 +7,13 @@ from gcn_amd import ops, prep, lib as L
 z = int(sys.argv[1]) if len(sys.argv) > 1 else 103
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 d = L.dims(z)
+DT = np.float64 if (len(sys.argv) > 3 and sys.argv[3] == 'f64') else np.float32
 rng = np.random.default_rng(0)
-cubes = torch.from_numpy(rng.random((B * 8, 9 * z)).astype(np.float32)).cuda()
+cubes = torch.from_numpy(rng.random((B * 8, 9 * z)).astype(DT)).cuda()
 onehot = np.zeros((B * 8, 13), dtype=np.int32); onehot[np.arange(B * 8), rng.integers(0, 13, B * 8)] = 1
 onehot = torch.from_numpy(onehot).cuda()
 import ctypes; ctypes.CDLL(None).srand(1)
-params = torch.from_numpy(prep.init_params(z, np.float32)).cuda()
+params = torch.from_numpy(prep.init_params(z, DT)).cuda()
 ws = ops.Workspace(); lv = torch.zeros(B, dtype=torch.float64, device="cuda")
 for i in range(50): ops.mbgd_step(params, cubes, onehot, (i % 8) * B, B, z, 0.0, loss_values=lv, workspace=ws)
 torch.cuda.synchronize(); t0 = time.perf_counter(); n = 500
