@@ -254,29 +254,33 @@ __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ param
     const int rot = (int)((row * 37) % pout);
     constexpr int UF = 16;    // W1 rows per reduce-scatter round of the backward walk
     constexpr int UFF = CCNN_FB_UFF;   // W1 rows in flight per thread in the forward walk
-    auto w1_rows = [&](int pb, V(&w)[UF]) {
+    // Both walks visit the rows in the same order: (g + rot) mod pout, then steps of G (mod pout).
+    // A running row number costs three instructions per row; rows past the end wrap onto valid
+    // ones, so the loads stay unconditional without a clamp.
+    const unsigned p_first = (unsigned)((g + rot) % pout);
+    unsigned p_run = p_first;
+    auto next_row = [&]() {
+        const unsigned p = p_run, t = p_run + G;
+        p_run = min(t, t - (unsigned)pout);   // t < pout: the difference wraps to a huge value
+        return p;
+    };
+    auto w1_rows = [&](V(&w)[UF]) {
 #pragma unroll
-        for (int u = 0; u < UF; u++) {
-            int p = min(pb + u * G + g, pout - 1) + rot;   // clamped: loads stay unconditional
-            p = p >= pout ? p - pout : p;
-            w[u] = W1v[(long)p * NQ + qc];
-        }
+        for (int u = 0; u < UF; u++) w[u] = W1v[next_row() * NQ + qc];
     };
     {
         V acc = {};
         for (int pb = 0; pb < pout; pb += G * UFF) {
             V w[UFF];
+            unsigned prow[UFF];
 #pragma unroll
             for (int u = 0; u < UFF; u++) {
-                int p = min(pb + u * G + g, pout - 1) + rot;
-                p = p >= pout ? p - pout : p;
-                w[u] = W1v[(long)p * NQ + qc];
+                prow[u] = next_row();
+                w[u] = W1v[prow[u] * NQ + qc];
             }
 #pragma unroll
             for (int u = 0; u < UFF; u++) {
-                int p = min(pb + u * G + g, pout - 1) + rot;
-                p = p >= pout ? p - pout : p;
-                const T x = (qv && pb + u * G + g < pout) ? pl[p] : T(0);
+                const T x = (qv && pb + u * G + g < pout) ? pl[prow[u]] : T(0);
                 acc += w[u] * x;
             }
         }
@@ -373,10 +377,11 @@ __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ param
                 delta[(f >> 4) * L.ldd + px[p] * LDWK + (f & 15)] = dv;
             }
         };
+        p_run = p_first;
         for (int pb = 0; pb < pout; pb += CCNN_FB_UFB * G * UF) {
             V w[CCNN_FB_UFB][UF];   // rows of several rounds in flight before the first is reduced
 #pragma unroll
-            for (int h = 0; h < CCNN_FB_UFB; h++) w1_rows(pb + h * G * UF, w[h]);
+            for (int h = 0; h < CCNN_FB_UFB; h++) w1_rows(w[h]);
 #pragma unroll
             for (int h = 0; h < CCNN_FB_UFB; h++) dpool_rows(pb + h * G * UF, w[h]);
         }
