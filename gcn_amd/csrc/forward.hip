@@ -246,19 +246,19 @@ size_t conv_smem(const ccnn_dims_t &d, int nwaves)
 // global loads are issued before the current chunk's MFMAs and stored after them.
 // Wave w owns sample tile w&1 and neuron tiles {0..3} (w<2) or {4..6}.
 // The epilogue runs from LDS: 8 lanes per sample, lane j producing outputs j and j+8.
-constexpr int FH_MS = 32;                      // samples per workgroup
+constexpr int FH_MS = 32;                      // samples per tile (16 when the list is too short to give every CU two tiles)
 constexpr int LDZ = H + 1;                     // z1/a1 rows in LDS (odd stride)
 
-template <typename T>
+template <typename T, int MS>
 struct FcHeadLds {
     static constexpr int wl = 0;                                   // [64][LDW1]   W1 chunk; later z1s[32][LDZ]
     static constexpr int pt = wl + PCHUNK * LDW1;                  // [32][LDP]    pool chunk
-    static constexpr int w2 = pt + ((FH_MS * LDP + 3) & ~3);       // [1300]       W2
+    static constexpr int w2 = pt + ((MS * LDP + 3) & ~3);       // [1300]       W2
     static constexpr int b1 = w2 + ((H * O + 3) & ~3);             // [100]
     static constexpr int b2 = b1 + H;                              // [16]
     static constexpr int es = b2 + 16;                             // [32][16]
-    static constexpr int ps = es + FH_MS * 16;                     // [32][16]
-    static constexpr int total = ps + FH_MS * 16;
+    static constexpr int ps = es + MS * 16;                     // [32][16]
+    static constexpr int total = ps + MS * 16;
     static constexpr size_t bytes = (size_t)total * sizeof(T);
 };
 
@@ -276,7 +276,7 @@ extern "C" int ccnn_debug_fc_wg(unsigned long long *out)
 #define FC_STAMP(k) do { } while (0)
 #endif
 
-template <typename T>
+template <typename T, int MS>
 __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params, int off_w1, int off_b1,
                                                    int off_w2, int off_b2, const T *__restrict__ pool,
                                                    int nrows, int pout, T *__restrict__ probs,
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_next;   // the workgroup's next tile, grabbed one tile ahead
-    typedef FcHeadLds<T> L;
+    typedef FcHeadLds<T, MS> L;
     typedef typename Vec16<T>::type V;
     constexpr int VW = Vec16<T>::W;
     T *base = reinterpret_cast<T *>(smem);
@@ -296,27 +296,37 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
     // out through eight counters (workgroup b uses counter b % 8, one eighth of the remaining
     // tiles each), so the grid can be exactly what the device holds and nobody idles through a
     // partly filled last round.
-    const int ntiles = (nrows + FH_MS - 1) / FH_MS;
+    const int ntiles = (nrows + MS - 1) / MS;
     const int xcd = blockIdx.x & 7;
     const int rem = ntiles > (int)gridDim.x ? ntiles - (int)gridDim.x : 0;
     const int per = (rem + 7) / 8;
     const int xlo = (int)gridDim.x + xcd * per;
     const int xhi = min(xlo + per, ntiles);
     int tile = blockIdx.x;
-    int r0 = tile * FH_MS;
-    int nb = min(FH_MS, nrows - r0);
+    int r0 = tile * MS;
+    int nb = min(MS, nrows - r0);
     const T *W1 = params + off_w1;
     const int nch = (pout + PCHUNK - 1) / PCHUNK;
     FC_STAMP(0);
 
-    const int mtile = wave & 1;
-    const int nt0 = (wave >> 1) ? 4 : 0;
+    // 32 samples: wave w owns sample tile w & 1 and neuron tiles {0..3} (w < 2) or {4..6};
+    // 16 samples: one sample tile, wave w owns neuron tiles {2w, 2w+1} (tile 7 does not exist)
+    constexpr int NJ = MS == 32 ? 4 : 2;
+    const int mtile = MS == 32 ? (wave & 1) : 0;
+    const int nt0 = MS == 32 ? ((wave >> 1) ? 4 : 0) : 2 * wave;
     const T *ap = pt + (mtile * 16 + col) * LDP + kq;
-    const T *bp = wl + kq * LDW1 + nt0 * 16 + col;
-    typename Mma<T>::acc_t acc[4];
+    const T *bp = wl + kq * LDW1 + col;
+    int boff[NJ];          // column offset of this wave's j-th neuron tile (a valid tile when it has none)
+    bool jlive[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        jlive[j] = nt0 + j < 7;
+        boff[j] = 16 * (jlive[j] ? nt0 + j : 0);
+    }
+    typename Mma<T>::acc_t acc[NJ];
 
     constexpr int NWV = (PCHUNK * H / VW + 255) / 256;      // W1 vectors per thread per chunk
-    constexpr int NPT = FH_MS * PCHUNK / 256;               // pool elements per thread per chunk
+    constexpr int NPT = MS * PCHUNK / 256;               // pool elements per thread per chunk
     V wreg[NWV];
     T preg[NPT];
     auto issue = [&](int c) {   // global loads of chunk c into registers (clamped, unconditional)
@@ -367,7 +377,7 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
         s_next = nx;   // read after the K loop's barriers
     }
 #pragma unroll
-    for (int j = 0; j < 4; j++) acc[j] = typename Mma<T>::acc_t{0, 0, 0, 0};
+    for (int j = 0; j < NJ; j++) acc[j] = typename Mma<T>::acc_t{0, 0, 0, 0};
     // neuron columns 100..111 of the W1 image are never loaded: keep them zero (the previous
     // tile's epilogue used the region)
     for (int e = tid; e < PCHUNK * (LDW1 - H); e += 256) wl[(e / (LDW1 - H)) * LDW1 + H + e % (LDW1 - H)] = 0;
@@ -378,17 +388,17 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
         __syncthreads();                     // chunk c is in LDS
         if (c + 1 < nch) issue(c + 1);       // next chunk's loads fly during the MFMAs
         for (int s = 0; s < PCHUNK / 4; s += 4) {
-            T a[4], b[4][4];
+            T a[4], b[4][NJ];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 a[u] = ap[4 * (s + u)];
 #pragma unroll
-                for (int j = 0; j < 4; j++) b[u][j] = bp[4 * (s + u) * LDW1 + 16 * (wave >> 1 && j == 3 ? 2 : j)];
+                for (int j = 0; j < NJ; j++) b[u][j] = bp[4 * (s + u) * LDW1 + boff[j]];
             }
 #pragma unroll
             for (int u = 0; u < 4; u++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) acc[j] = Mma<T>::mma(a[u], b[u][j], acc[j]);
+                for (int j = 0; j < NJ; j++) acc[j] = Mma<T>::mma(a[u], b[u][j], acc[j]);
         }
         __syncthreads();                     // everyone is done reading chunk c
         if (c + 1 < nch) commit(c + 1);
@@ -399,23 +409,26 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
     const int tile_next = s_next;
     const int r0_done = r0, nb_done = nb;
     if (tile_next >= 0) {   // the next tile's first chunk flies during this tile's epilogue
-        r0 = tile_next * FH_MS;
-        nb = min(FH_MS, nrows - r0);
+        r0 = tile_next * MS;
+        nb = min(MS, nrows - r0);
         issue(0);
     }
     T *z1s = wl;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < NJ; j++) {
         const int n = (nt0 + j) * 16 + col;
-        if (n < H && !(wave >> 1 && j == 3)) {
+        if (n < H && jlive[j]) {
 #pragma unroll
             for (int r = 0; r < 4; r++) z1s[(mtile * 16 + Mma<T>::row(lane, r)) * LDZ + n] = acc[j][r];
         }
     }
     __syncthreads();
-    const int s = tid >> 3, j8 = tid & 7;
+    const int j8 = tid & 7;
+    const bool has_s = (tid >> 3) < MS;            // 8 lanes per sample: with 16 samples half the threads idle
+    const int s = has_s ? tid >> 3 : 0;
     T *zr = z1s + s * LDZ;
-    for (int n = j8; n < H; n += 8) zr[n] = act(zr[n] + b1s[n]);   // gcn_mbgd_fp64.cu:302
+    if (has_s)
+        for (int n = j8; n < H; n += 8) zr[n] = act(zr[n] + b1s[n]);   // gcn_mbgd_fp64.cu:302
     __syncthreads();
     const int o0 = j8, o1 = j8 + 8;          // lane j8 produces outputs j8 and j8+8 (the latter for j8 < 5)
     const bool has1 = o1 < O;
@@ -426,19 +439,23 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
         m1 = m1 + w2s[(has1 ? o1 : o0) + i * O] * a;
     }
     const T e0 = rexp(m0 + b2s[o0]), e1 = rexp(m1 + b2s[has1 ? o1 : o0]);
-    es[s * 16 + o0] = e0;
-    if (has1) es[s * 16 + o1] = e1;
+    if (has_s) {
+        es[s * 16 + o0] = e0;
+        if (has1) es[s * 16 + o1] = e1;
+    }
     __syncthreads();
     const T sum = tree13(es + s * 16);
     const T p0 = e0 / sum, p1 = e1 / sum;
-    ps[s * 16 + o0] = p0;
-    if (has1) ps[s * 16 + o1] = p1;
-    if (s < nb_done && probs) {
+    if (has_s) {
+        ps[s * 16 + o0] = p0;
+        if (has1) ps[s * 16 + o1] = p1;
+    }
+    if (has_s && s < nb_done && probs) {
         probs[(long)(r0_done + s) * O + o0] = p0;
         if (has1) probs[(long)(r0_done + s) * O + o1] = p1;
     }
     __syncthreads();
-    if (argmax && j8 == 0 && s < nb_done) {
+    if (argmax && has_s && j8 == 0 && s < nb_done) {
         // count_err: running max starts at 0, strict '>' (gcn_mbgd_fp64.cu:636-647)
         T mx = 0;
         int idx = 0;
@@ -586,14 +603,20 @@ int forward_impl(const T *params, const T *cubes, long n, int z, T *probs, int *
         }
     }
     if (nwv == 0) return CCNN_E_RANGE;
-    if (int e = allow_smem(fc_head_fwd<T>, FcHeadLds<T>::bytes)) return e;
-    const int fc_resident = resident_blocks(reinterpret_cast<const void *>(fc_head_fwd<T>), 256, FcHeadLds<T>::bytes);
-    if (fc_resident <= 0) return CCNN_E_RANGE;
+    if (int e = allow_smem(fc_head_fwd<T, 32>, FcHeadLds<T, 32>::bytes)) return e;
+    if (int e = allow_smem(fc_head_fwd<T, 16>, FcHeadLds<T, 16>::bytes)) return e;
+    const int fc_res32 = resident_blocks(reinterpret_cast<const void *>(fc_head_fwd<T, 32>), 256, FcHeadLds<T, 32>::bytes);
+    const int fc_res16 = resident_blocks(reinterpret_cast<const void *>(fc_head_fwd<T, 16>), 256, FcHeadLds<T, 16>::bytes);
+    if (fc_res32 <= 0 || fc_res16 <= 0) return CCNN_E_RANGE;
     for (long s0 = 0; s0 < n; s0 += rows) {
         const int nr = (int)((n - s0) < rows ? (n - s0) : rows);
         const int groups = (nr + nwv - 1) / nwv;
         const int pg = groups < resident ? groups : resident;
-        const int ntiles = (nr + FH_MS - 1) / FH_MS;
+        // 16-sample tiles while 32-sample ones would leave CUs with fewer than two workgroups
+        const bool small = (nr + FH_MS - 1) / FH_MS < 512;
+        const int ms = small ? 16 : FH_MS;
+        const int ntiles = (nr + ms - 1) / ms;
+        const int fc_resident = small ? fc_res16 : fc_res32;
         const int fg = ntiles < fc_resident ? ntiles : fc_resident;
         if ((long)nr > 3L * pg * nwv || ntiles > fg) {   // work beyond the fixed shares is handed out through the counters
             hipError_t e = hipMemsetAsync(w.ctr, 0, 8 * CONV_CTR_STRIDE * sizeof(int), st);
@@ -605,7 +628,8 @@ int forward_impl(const T *params, const T *cubes, long n, int z, T *probs, int *
         }
         CCNN_LAUNCH_CHECK();
         {
-            launch("fc_head_fwd", fc_head_fwd<T>, dim3(fg), dim3(256), FcHeadLds<T>::bytes, st,
+            launch("fc_head_fwd", small ? fc_head_fwd<T, 16> : fc_head_fwd<T, 32>, dim3(fg), dim3(256),
+                   small ? FcHeadLds<T, 16>::bytes : FcHeadLds<T, 32>::bytes, st,
                    params, d.off_w1, d.off_b1, d.off_w2, d.off_b2, w.pool, nr, d.pout,
                    probs ? probs + s0 * O : nullptr, argmax ? argmax + s0 : nullptr, w.ctr);
         }
