@@ -187,6 +187,13 @@ __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ param
     // Issue every global load this phase needs (filters, cube, and the small output-layer
     // operands used much later) before touching LDS, so one memory round trip covers them.
     constexpr int NW = NT / 64;
+    constexpr int NCREG = (NB * CCNN_MAX_BANDS + NT - 1) / NT;   // the cube comes from HBM, cold: first in the queue
+    T creg[NCREG];
+    {
+        const T *src = cubes + (first + row) * (long)d.cube;
+#pragma unroll
+        for (int u = 0; u < NCREG; u++) creg[u] = src[min(u * NT + tid, d.cube - 1)];   // clamped, unconditional
+    }
     constexpr int NWREG = (F * K + NT - 1) / NT;
     T wreg[NWREG];
 #pragma unroll
@@ -207,11 +214,21 @@ __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ param
     const T b2v = params[d.off_b2 + min(o8, O - 1)];
     const T bias0 = params[d.off_b0 + col];
     const T bias1 = params[d.off_b0 + min(16 + col, F - 1)];
+    FB_TICK(11);
     if (tid < O) lab[tid] = lab_g;
+    FB_TICK(12);
     for (int e = d.cube + tid; e < conv_cube_pad(re); e += NT) cube[e] = 0;
-    for (int e = tid; e < WL_LEN; e += NT) wl[e] = 0;
-    stage<8, NT>(cubes + (first + row) * (long)d.cube, d.cube, tid, [&](int e, T v) { cube[e] = v; });
+    // zeros the filter scatter below does not overwrite: the second tile (filters 20..31) and tap 171 of the first
+    for (int e = WL_TILE - LDWK + tid; e < WL_LEN; e += NT) wl[e] = 0;
+    FB_TICK(13);
+#pragma unroll
+    for (int u = 0; u < NCREG; u++) {
+        const int e = u * NT + tid;
+        if (e < d.cube) cube[e] = creg[u];
+    }
+    FB_TICK(14);
     __syncthreads();
+    FB_TICK(15);
 #pragma unroll
     for (int u = 0; u < NWREG; u++) {
         const int e = u * NT + tid;
