@@ -38,7 +38,11 @@ constexpr int LDWK = 16;    // conv filters: two tap-major tiles [172 taps][16 f
                             // half-wave (a filter-major [f][175] tile costs a 2-way conflict per read).
 constexpr int WL_TILE = 172 * LDWK;  // tap 171 and filters 20..31 are zero
 constexpr int WL_LEN = 2 * WL_TILE;
-__host__ __device__ inline int wl_index(int f, int k) { return (f >> 4) * WL_TILE + k * LDWK + (f & 15); }
+// Within a tap's row the 16 filters are stored at column (f ^ tap) & 15: the conv's reads (16
+// lanes = 16 filters of one tap) stay a permutation of the row's banks, and the staging writes
+// (consecutive lanes = consecutive taps of one filter, 16 words apart) no longer all land in two
+// banks (a 32-way conflict) but spread over all of them.
+__host__ __device__ inline int wl_index(int f, int k) { return (f >> 4) * WL_TILE + k * LDWK + ((f ^ k) & 15); }
 constexpr int LDW1 = 112;   // W1 chunk       [64 p][112], fc_head_fwd (lanes walk n)
 constexpr int LDP = 79;     // pool tile      [16 b][79]
 constexpr int KSTEPS0 = (K + 3) / 4;   // 43 k-steps cover the 171 taps
@@ -256,30 +260,35 @@ __device__ __forceinline__ void conv_pool_tiles(const T *cube, int cube_stride, 
 {
     const int col = lane & 15, kq = lane >> 4;
     const int mt = conv_mtiles(re);
-    const T *bp0 = wl + kq * LDWK + col;
-    const T *bp1 = bp0 + WL_TILE;
+    // B operand of k-step s: tap 4 s + kq, filter col, stored at column (col ^ tap) & 15
+    // (wl_index) = (col ^ kq) ^ (4 s & 12): one pointer per s & 3
+    const T *bq[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) bq[u] = wl + kq * LDWK + ((col ^ kq) ^ (4 * u));
+    constexpr int KMAIN = KSTEPS0 & ~3;
     if (split) {
         // one filter half per job: twice the jobs for workgroups with more waves than position tiles
         for (int job = wave; job < 2 * nsamp * mt; job += nwaves) {
             const int half = job & 1, pj = job >> 1;
             const int sidx = pj / mt, tile = pj - sidx * mt;
             const T *ap = cube + sidx * cube_stride + WSTEP * (tile * 16 + col) + kq;
-            const T *bp = half ? bp1 : bp0;
+            const int hoff = half ? WL_TILE : 0;
             typename Mma<T>::acc_t acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};   // two chains: even / odd k-steps
-            int s = 0;
-            for (; s + 4 <= KSTEPS0; s += 4) {
+            for (int s = 0; s < KMAIN; s += 4) {
                 T a[4], b[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     a[u] = ap[4 * (s + u)];
-                    b[u] = bp[4 * (s + u) * LDWK];
+                    b[u] = bq[u][hoff + 4 * (s + u) * LDWK];
                 }
                 acc = Mma<T>::mma(a[0], b[0], acc);
                 acc2 = Mma<T>::mma(a[1], b[1], acc2);
                 acc = Mma<T>::mma(a[2], b[2], acc);
                 acc2 = Mma<T>::mma(a[3], b[3], acc2);
             }
-            for (; s < KSTEPS0; s++) acc = Mma<T>::mma(ap[4 * s], bp[4 * s * LDWK], acc);
+#pragma unroll
+            for (int u = 0; u < KSTEPS0 - KMAIN; u++)
+                acc = Mma<T>::mma(ap[4 * (KMAIN + u)], bq[u][hoff + 4 * (KMAIN + u) * LDWK], acc);
 #pragma unroll
             for (int r = 0; r < 4; r++) acc[r] += acc2[r];
             auto put1 = [&](int f, int m, T v, int bt) { put(sidx, f, m, v, bt); };
@@ -292,14 +301,13 @@ __device__ __forceinline__ void conv_pool_tiles(const T *cube, int cube_stride, 
         const int sidx = job / mt, tile = job - sidx * mt;
         const T *ap = cube + sidx * cube_stride + WSTEP * (tile * 16 + col) + kq;
         typename Mma<T>::acc_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-        int s = 0;
-        for (; s + 4 <= KSTEPS0; s += 4) {   // operands of four k-steps in flight
+        for (int s = 0; s < KMAIN; s += 4) {   // operands of four k-steps in flight
             T a[4], b0[4], b1[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 a[u] = ap[4 * (s + u)];
-                b0[u] = bp0[4 * (s + u) * LDWK];
-                b1[u] = bp1[4 * (s + u) * LDWK];
+                b0[u] = bq[u][4 * (s + u) * LDWK];
+                b1[u] = bq[u][WL_TILE + 4 * (s + u) * LDWK];
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -307,10 +315,11 @@ __device__ __forceinline__ void conv_pool_tiles(const T *cube, int cube_stride, 
                 acc1 = Mma<T>::mma(a[u], b1[u], acc1);
             }
         }
-        for (; s < KSTEPS0; s++) {
-            const T a = ap[4 * s];
-            acc0 = Mma<T>::mma(a, bp0[4 * s * LDWK], acc0);
-            acc1 = Mma<T>::mma(a, bp1[4 * s * LDWK], acc1);
+#pragma unroll
+        for (int u = 0; u < KSTEPS0 - KMAIN; u++) {
+            const T a = ap[4 * (KMAIN + u)];
+            acc0 = Mma<T>::mma(a, bq[u][4 * (KMAIN + u) * LDWK], acc0);
+            acc1 = Mma<T>::mma(a, bq[u][WL_TILE + 4 * (KMAIN + u) * LDWK], acc1);
         }
         auto put1 = [&](int f, int m, T v, int bt) { put(sidx, f, m, v, bt); };
         pool_tile(acc0, bias0, col, true, tile * 16, re, lane, put1);

@@ -215,11 +215,11 @@ __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ param
     const T bias0 = params[d.off_b0 + col];
     const T bias1 = params[d.off_b0 + min(16 + col, F - 1)];
     FB_TICK(11);
-    if (tid < O) lab[tid] = lab_g;
-    FB_TICK(12);
     for (int e = d.cube + tid; e < conv_cube_pad(re); e += NT) cube[e] = 0;
     // zeros the filter scatter below does not overwrite: the second tile (filters 20..31) and tap 171 of the first
     for (int e = WL_TILE - LDWK + tid; e < WL_LEN; e += NT) wl[e] = 0;
+    FB_TICK(12);
+    if (tid < O) lab[tid] = lab_g;   // the first use of a loaded value: after the zeroing, which needs none
     FB_TICK(13);
 #pragma unroll
     for (int u = 0; u < NCREG; u++) {

@@ -29,5 +29,5 @@ if os.environ.get("CCNN_FB_TIMING"):
     names = ["stage", "conv+pool", "fc1", "a1", "out layer", "softmax", "delta1", "dpool", "conv_bwd", "bias+tail"]
     print("  ".join(f"{names[k]}={(t[k + 1] - t[k]) * 10}ns" for k in range(10)), f"total={(t[10] - t[0]) * 10}ns")
     if t[11]:
-        print("inside stage: loads issued +%dns, labels stored (first wait) +%dns, LDS zeroed +%dns, cube staged +%dns, barrier +%dns, filters scattered + barrier +%dns"
+        print("inside stage: loads issued +%dns, LDS zeroed +%dns, labels stored (first wait) +%dns, cube staged +%dns, barrier +%dns, filters scattered + barrier +%dns"
               % tuple((t[k] - t[0]) * 10 for k in (11, 12, 13, 14, 15, 1)))
