@@ -313,7 +313,7 @@ __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ param
         T zsum = 0;
 #pragma unroll
         for (int gg = 0; gg < G; gg++) zsum = zsum + z1p[gg * H + tid];
-        a = 2 / (1 + 1 / rexp((zsum + b1v) * 2)) - 1;   // gcn_mbgd_fp64.cu:302
+        a = act(zsum + b1v);   // gcn_mbgd_fp64.cu:302
         a1s[tid] = a;
         a1_g[row * H + tid] = a;
     }
@@ -342,7 +342,6 @@ __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ param
         const T dv = (p - lab[tid]) / O;   // gcn_mbgd_fp64.cu:352
         d2s[tid] = dv;
         d2_g[row * O + tid] = dv;
-        loss_terms(p, lab[tid], &lta[tid], &ltb[tid]);
     }
     // the filters are dead: clear their region for the scattered deltas
     for (int e = tid; e < 2 * L.ldd; e += NT) wl[e] = 0;
@@ -356,6 +355,11 @@ __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ param
         const T dv = tree13(prod) * (1 + a) * (1 - a);
         d1s[tid] = dv;
         d1_g[row * H + tid] = dv;
+    }
+    // the loss terms (a log and an exp each) are nobody's input: an idle wave computes them here
+    if (tid >= NT - 64 && tid < NT - 64 + O) {
+        const int o = tid - (NT - 64);
+        loss_terms(ps[o], lab[o], &lta[o], &ltb[o]);
     }
     __syncthreads();
     FB_TICK(7);
