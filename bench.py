@@ -316,7 +316,7 @@ def main():
             if name not in work or cnt == 0:
                 continue
             bound, per_px = work[name]
-            # FWD_CHUNK-sized launches: a pass over te_n pixels may be several launches
+            # a pass over te_n pixels may be several launches (the library works through its workspace in chunks)
             passes = preps if name in ("conv_pool_fwd", "fc_head_fwd", "gather_tile") else cnt
             per_launch = (3.0 + (2.0 * world if name == "allreduce_apply" else 0.0)) * d.nparams * 4
             units = per_launch * cnt if per_px is None else per_px * pixels[name] * passes

@@ -39,9 +39,11 @@ int raise_smem_limit(const void *fn, size_t bytes)
 // (conv_pool_wave), and holds the next sample's cube in registers meanwhile.  The waves of a
 // workgroup share only the staged filters, so after the prologue there is no workgroup barrier:
 // the waves drift apart and one wave's loads, activations and stores run under the others'
-// matrix instructions.  (With 4 samples per 256-thread workgroup and two barriers per group the
-// matrix pipes idled during everything that was not an MFMA: 297 us per 65536 Pavia samples,
-// 125 us of it with the MFMAs removed.)
+// matrix instructions.  What made the kernel faster than its predecessor (4 samples per
+// 256-thread workgroup, two barriers per group, 297 us per 65536 Pavia samples) was, in order of
+// size: fewer MFMA instructions (packed tile, ccnn_device.h), a grid of exactly the resident
+// workgroups, rows handed out on demand, and 16-byte pooled stores; the barrier-free structure
+// by itself measured the same as the barriers at equal instruction count.
 // pool[row][f*mre + m] = pooled value.
 //
 // NREG >= ceil(cube_len/64) is a template parameter so that the prefetch is straight-line code:
@@ -237,14 +239,13 @@ size_t conv_smem(const ccnn_dims_t &d, int nwaves)
 }
 
 // ---------------------------------------------------------------------------
-// FC1 + tanh + output layer + softmax + count_err argmax for 32 samples per
-// workgroup (fully_connect, output_and_dvalue(false), count_err:
+// FC1 + tanh + output layer + softmax + count_err argmax, a tile of 32 (short lists: 16) samples
+// at a time per persistent workgroup (fully_connect, output_and_dvalue(false), count_err:
 // gcn_mbgd_fp64.cu:271-354, 628-652).
 //
 // FC1 is a [32 x Pout] x [Pout x 100] MFMA product: the K loop walks W1 in chunks of
 // 64 pooled features (25.6 KB, contiguous in W1) staged through LDS; the next chunk's
 // global loads are issued before the current chunk's MFMAs and stored after them.
-// Wave w owns sample tile w&1 and neuron tiles {0..3} (w<2) or {4..6}.
 // The epilogue runs from LDS: 8 lanes per sample, lane j producing outputs j and j+8.
 constexpr int FH_MS = 32;                      // samples per tile (16 when the list is too short to give every CU two tiles)
 constexpr int LDZ = H + 1;                     // z1/a1 rows in LDS (odd stride)
