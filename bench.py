@@ -287,7 +287,29 @@ def main():
         torch.cuda.synchronize()
         sgd_pps = ns / (time.perf_counter() - t2)
         assert torch.isfinite(p64).all()
-        del cubes64, p64
+        del cubes64
+
+    # ---- fp64 MBGD (the reference's canonical build, gcn_mbgd_fp64.cu: B = 100) on the same cubes, rank 0
+    mbgd64_pps = None
+    if rank == 0:
+        B64 = 100
+        n64 = min(slice_len // B64, 40)
+        c64 = cubes[:n64 * B64].double()
+        o64 = onehot_d[:n64 * B64].contiguous()
+        p64 = torch.from_numpy(prep.init_params(z, np.float64, B64)).to(dev)
+        l64 = torch.zeros(B64, dtype=torch.float64, device=dev)
+        w64 = ops.Workspace(dev)
+        for i in range(n64):
+            ops.mbgd_step(p64, c64, o64, i * B64, B64, z, 0.5, loss_values=l64, workspace=w64)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for r in range(10):
+            for i in range(n64):
+                ops.mbgd_step(p64, c64, o64, i * B64, B64, z, 0.5, loss_values=l64, workspace=w64)
+        torch.cuda.synchronize()
+        mbgd64_pps = 10 * n64 * B64 / (time.perf_counter() - t2)
+        assert torch.isfinite(p64).all()
+        del c64, p64
 
     # ---- per-kernel timing (HIP events on the launch stream, recorded inside the library):
     # the same training steps, one inference pass and one gather of the training list
@@ -376,6 +398,7 @@ def main():
             "infer_from_scene_pixels_per_s": round(infer_scene_pps, 1),
             "infer_full_scene_pixels_per_s": round(infer_full_pps, 1),
             "sgd_fp64_pixels_per_s": round(sgd_pps, 1),
+            "mbgd_fp64_b100_pixels_per_s": round(mbgd64_pps, 1),
             "roofline": roof,
             "cpu_baseline": cpu,
             "kernels": kernels,
