@@ -111,6 +111,8 @@ for i in range(nsteps):
                "W2": (dd.off_w2, dd.off_b2), "b2": (dd.off_b2, dd.nparams)}
         print(f"  step {i}: " + ", ".join(f"{k} err {np.abs(ps_h[a:b] - p_ref[a:b]).max():.2e} (max |w| {np.abs(p_ref[a:b]).max():.2e})"
                                          for k, (a, b) in grp.items()))
+        e0 = np.abs(ps_h[:dd.off_b0] - p_ref[:dd.off_b0]).reshape(20, 171).max(axis=1)
+        print("    filters whose error exceeds 1e-7:", [(int(f), float(f"{e0[f]:.2e}")) for f in np.nonzero(e0 > 1e-7)[0]])
     worst_w = max(worst_w, e_step)
     worst_l = max(worst_l, rel(lv.cpu().numpy(), np.asarray(lref, dtype=np.float64)))
 pr_ref, am_ref = orc.forward(p_ref, ref_test, z)
