@@ -74,50 +74,57 @@ for ep in range(2):
 print(f"MBGD 2 epochs x {T // B} steps: weights rel err {rel(p_gpu.cpu().numpy(), p_ref):.2e}, worst per-step loss rel err {worst_loss:.2e}; "
       f"GPU {t_gpu * 1e3:.0f} ms (with a sync per step), oracle {t_cpu:.1f} s")
 
-# ---- fp32 MBGD on a Pavia-U-shaped scene (gcn_mbgd_fp32.cu), B = 128: per-step error with the GPU
-# restarted from the oracle's weights every step, then one free-running epoch and the accuracy
+# ---- fp32 MBGD on Pavia-U- and Indian-Pines-shaped scenes (gcn_mbgd_fp32.cu), B = 128: per-step error
+# with the GPU restarted from the oracle's weights every step, then one free-running epoch and the accuracy
 del sc, g_train, g_test
-x, y, z, nl = synth.SCENES["pavia_u"]
-rng = np.random.default_rng(20244)
-labels = synth.make_labels(x, y, nl, rng)
-scene = synth.make_scene(x, y, z, np.float32, rng)
-di = orc.scan_labels(labels, x, y)
-tr9, te9, onehot, tl = orc.build_index(labels, di, x, y)
-orc.shuffle(tr9, onehot, 9)
-T, B = len(onehot), 128
-ref_train, ref_test = orc.gather(scene, tr9, x, y, z), orc.gather(scene, te9, x, y, z)
-sc = torch.from_numpy(scene).to(dev)
-g_train = ops.gather(sc, torch.from_numpy(tr9).to(dev), x, y, z)
-g_test = ops.gather(sc, torch.from_numpy(te9).to(dev), x, y, z, sort=False)
-print(f"pavia_u: train {T} / test {len(tl)}; cubes bit-exact: {np.array_equal(g_train.cpu().numpy(), ref_train)} / "
-      f"{np.array_equal(g_test.cpu().numpy(), ref_test)}")
-oh_d = torch.from_numpy(onehot).to(dev)
-orc.srand(9)
-p_ref = orc.init_params_f32(z)
-p_free = torch.from_numpy(p_ref.copy()).to(dev)
-lv = torch.zeros(B, dtype=torch.float64, device=dev)
-worst_w = worst_l = 0.0
-nsteps = T // B
-for i in range(nsteps):
-    p_step = torch.from_numpy(p_ref.copy()).to(dev)          # this step from the oracle's weights
-    ops.mbgd_step(p_step, g_train, oh_d, i * B, B, z, 0.04, loss_values=lv, workspace=ws)
-    ops.mbgd_step(p_free, g_train, oh_d, i * B, B, z, 0.04, workspace=ws)
-    lref, _, _ = orc.mbgd_step(p_ref, ref_train, onehot, i * B, B, z, np.float32(0.04), want_grad=False)
-    e_step = rel(p_step.cpu().numpy(), p_ref)
-    if e_step > worst_w and os.environ.get("PARITY_DETAIL"):
-        dd = orc.dims(z)
-        ps_h = p_step.cpu().numpy()
-        grp = {"W0": (0, dd.off_b0), "b0": (dd.off_b0, dd.off_w1), "W1": (dd.off_w1, dd.off_b1), "b1": (dd.off_b1, dd.off_w2),
-               "W2": (dd.off_w2, dd.off_b2), "b2": (dd.off_b2, dd.nparams)}
-        print(f"  step {i}: " + ", ".join(f"{k} err {np.abs(ps_h[a:b] - p_ref[a:b]).max():.2e} (max |w| {np.abs(p_ref[a:b]).max():.2e})"
-                                         for k, (a, b) in grp.items()))
-        e0 = np.abs(ps_h[:dd.off_b0] - p_ref[:dd.off_b0]).reshape(20, 171).max(axis=1)
-        print("    filters whose error exceeds 1e-7:", [(int(f), float(f"{e0[f]:.2e}")) for f in np.nonzero(e0 > 1e-7)[0]])
-    worst_w = max(worst_w, e_step)
-    worst_l = max(worst_l, rel(lv.cpu().numpy(), np.asarray(lref, dtype=np.float64)))
-pr_ref, am_ref = orc.forward(p_ref, ref_test, z)
-_, am = ops.forward(p_free, g_test, z)
-acc_ref, acc = np.mean(am_ref + 1 == tl) * 100, np.mean(am.cpu().numpy() + 1 == tl) * 100
-print(f"fp32 MBGD, {nsteps} steps: worst per-step weights rel err {worst_w:.2e}, loss {worst_l:.2e}; after the free-running epoch "
-      f"weights differ by {rel(p_free.cpu().numpy(), p_ref):.2e}, accuracy {acc:.3f} % vs oracle {acc_ref:.3f} %, "
-      f"argmax differs on {int((am.cpu().numpy() != am_ref).sum())} of {len(tl)} pixels")
+
+
+def fp32_epoch(name, seed):
+    x, y, z, nl = synth.SCENES[name]
+    rng = np.random.default_rng(seed)
+    labels = synth.make_labels(x, y, nl, rng)
+    scene = synth.make_scene(x, y, z, np.float32, rng)
+    di = orc.scan_labels(labels, x, y)
+    tr9, te9, onehot, tl = orc.build_index(labels, di, x, y)
+    orc.shuffle(tr9, onehot, 9)
+    T, B = len(onehot), 128
+    ref_train, ref_test = orc.gather(scene, tr9, x, y, z), orc.gather(scene, te9, x, y, z)
+    sc = torch.from_numpy(scene).to(dev)
+    g_train = ops.gather(sc, torch.from_numpy(tr9).to(dev), x, y, z)
+    g_test = ops.gather(sc, torch.from_numpy(te9).to(dev), x, y, z, sort=False)
+    print(f"{name}: train {T} / test {len(tl)}; cubes bit-exact: {np.array_equal(g_train.cpu().numpy(), ref_train)} / "
+          f"{np.array_equal(g_test.cpu().numpy(), ref_test)}")
+    oh_d = torch.from_numpy(onehot).to(dev)
+    orc.srand(9)
+    p_ref = orc.init_params_f32(z)
+    p_free = torch.from_numpy(p_ref.copy()).to(dev)
+    lv = torch.zeros(B, dtype=torch.float64, device=dev)
+    worst_w = worst_l = 0.0
+    nsteps = T // B
+    for i in range(nsteps):
+        p_step = torch.from_numpy(p_ref.copy()).to(dev)          # this step from the oracle's weights
+        ops.mbgd_step(p_step, g_train, oh_d, i * B, B, z, 0.04, loss_values=lv, workspace=ws)
+        ops.mbgd_step(p_free, g_train, oh_d, i * B, B, z, 0.04, workspace=ws)
+        lref, _, _ = orc.mbgd_step(p_ref, ref_train, onehot, i * B, B, z, np.float32(0.04), want_grad=False)
+        e_step = rel(p_step.cpu().numpy(), p_ref)
+        if e_step > worst_w and os.environ.get("PARITY_DETAIL"):
+            dd = orc.dims(z)
+            ps_h = p_step.cpu().numpy()
+            grp = {"W0": (0, dd.off_b0), "b0": (dd.off_b0, dd.off_w1), "W1": (dd.off_w1, dd.off_b1), "b1": (dd.off_b1, dd.off_w2),
+                   "W2": (dd.off_w2, dd.off_b2), "b2": (dd.off_b2, dd.nparams)}
+            print(f"  step {i}: " + ", ".join(f"{k} err {np.abs(ps_h[a:b] - p_ref[a:b]).max():.2e} (max |w| {np.abs(p_ref[a:b]).max():.2e})"
+                                             for k, (a, b) in grp.items()))
+            e0 = np.abs(ps_h[:dd.off_b0] - p_ref[:dd.off_b0]).reshape(20, 171).max(axis=1)
+            print("    filters whose error exceeds 1e-7:", [(int(f), float(f"{e0[f]:.2e}")) for f in np.nonzero(e0 > 1e-7)[0]])
+        worst_w = max(worst_w, e_step)
+        worst_l = max(worst_l, rel(lv.cpu().numpy(), np.asarray(lref, dtype=np.float64)))
+    pr_ref, am_ref = orc.forward(p_ref, ref_test, z)
+    _, am = ops.forward(p_free, g_test, z)
+    acc_ref, acc = np.mean(am_ref + 1 == tl) * 100, np.mean(am.cpu().numpy() + 1 == tl) * 100
+    print(f"fp32 MBGD, {nsteps} steps: worst per-step weights rel err {worst_w:.2e}, loss {worst_l:.2e}; after the free-running epoch "
+          f"weights differ by {rel(p_free.cpu().numpy(), p_ref):.2e}, accuracy {acc:.3f} % vs oracle {acc_ref:.3f} %, "
+          f"argmax differs on {int((am.cpu().numpy() != am_ref).sum())} of {len(tl)} pixels")
+
+
+fp32_epoch("pavia_u", 20244)
+fp32_epoch("indian_pines", 20243)
