@@ -142,19 +142,23 @@ def main():
                 print(f"one-shot exchange unavailable ({e}); using RCCL", file=sys.stderr)
             comm = None
 
+    # route of the N>1 step: "instep" (exchange inside the reduction kernel), "standalone" (gradient,
+    # then the library's exchange + update kernel) or "rccl" (gradient, RCCL all-reduce, update)
+    mode = "instep" if comm is not None else "rccl"
+
     def step(i):
         b = i % nb
         if not use_dist:
             # gradient + update fused (nothing has to happen in between on one GPU)
             ops.mbgd_step(params, cubes, onehot_d, b * B, B, z, lr, loss_values=loss_ring[b], workspace=ws)
+        elif mode == "instep":
+            # two launches: the reduction kernel trades its sums with the other ranks and updates
+            ops.mbgd_step(params, cubes, onehot_d, b * B, B, z, lr, loss_values=loss_ring[b], workspace=ws, comm=comm)
         else:
-            if comm is not None:
-                # two launches: the reduction kernel trades its sums with the other ranks and updates
-                ops.mbgd_step(params, cubes, onehot_d, b * B, B, z, lr, loss_values=loss_ring[b], workspace=ws,
-                              comm=comm)
+            ops.mbgd_grad(params, cubes, onehot_d, b * B, B, z, grad=grad, loss_values=loss_ring[b], workspace=ws)
+            if mode == "standalone":
+                comm.allreduce_update(params, grad, lr, z)
             else:
-                ops.mbgd_grad(params, cubes, onehot_d, b * B, B, z, grad=grad, loss_values=loss_ring[b],
-                              workspace=ws)
                 dist.all_reduce(grad)
                 ops.update(params, grad, lr, z)
 
@@ -181,33 +185,46 @@ def main():
     fence()
     calibration = None
     if comm is not None:
-        # The exchange passed its self-test.  Had it stalled during warm-up anyway, finish on RCCL;
-        # otherwise let the rest of the warm-up decide which of the two routes this node runs
-        # faster (untimed steps of the same work; every rank sees the same max-over-ranks times).
+        # The exchange passed its self-tests.  Had it stalled during warm-up anyway, finish on RCCL;
+        # otherwise let the rest of the warm-up decide which of the three routes this node runs
+        # fastest (untimed steps of the same work; every rank sees the same max-over-ranks times).
         st_all = [None] * world
         dist.all_gather_object(st_all, comm.status())
-        keep = not any(st_all)
-        if not keep and rank == 0:
-            print("one-shot exchange timed out during warm-up; using RCCL", file=sys.stderr)
-        if keep and os.environ.get("CCNN_ALLREDUCE", "") != "oneshot":
+        if any(st_all):
+            if rank == 0:
+                print("one-shot exchange timed out during warm-up; using RCCL", file=sys.stderr)
+            mode = "rccl"
+        elif os.environ.get("CCNN_ALLREDUCE", "") != "oneshot":
             ncal = max(args.warmup, 50)
-            t_one = timed(ncal)
-            held, comm = comm, None
-            for i in range(20):
-                step(i)
-            t_rccl = timed(ncal)
-            comm = held
-            calibration = {"steps": ncal, "oneshot_us_per_step": round(t_one / ncal * 1e6, 2),
-                           "rccl_us_per_step": round(t_rccl / ncal * 1e6, 2)}
-            keep = t_one <= t_rccl
-        if not keep:
+            times = {}
+            def stalled():
+                fence()
+                st = [None] * world
+                dist.all_gather_object(st, comm.status())
+                return any(st)
+
+            for m in ("instep", "standalone", "rccl"):
+                mode = m
+                for i in range(3):
+                    step(i)
+                if m != "rccl" and stalled():            # a wait timed out: not a candidate, and not worth 200 more waits
+                    times[m] = float("inf")
+                    continue
+                for i in range(20):
+                    step(i)
+                times[m] = timed(ncal)
+                if m != "rccl" and stalled():
+                    times[m] = float("inf")
+            calibration = {"steps": ncal, **{f"{m}_us_per_step": (round(t / ncal * 1e6, 2) if t != float("inf") else None)
+                                             for m, t in times.items()}}
+            mode = min(times, key=times.get)
+        if mode == "rccl":
             comm.close()
             comm = None
-        if calibration is not None or not keep:
-            params.copy_(torch.from_numpy(params_h).to(dev))
-            for i in range(args.warmup):
-                step(i)
-            fence()
+        params.copy_(torch.from_numpy(params_h).to(dev))
+        for i in range(args.warmup):
+            step(i)
+        fence()
     dt = timed(args.steps, args.warmup)
     train_pps = world * B * args.steps / dt
     assert torch.isfinite(params).all(), "training diverged"
@@ -391,8 +408,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}-shaped {x}x{y}x{z} fp32 MBGD", "batch_per_gpu": B,
                        "global_batch": B * world, "train_pixels": T, "parallelism": f"dp{world}",
-                       "exchange": ("none" if not use_dist else "xgmi one-shot exchange inside the reduction kernel"
-                                    if comm is not None else "rccl all-reduce + update"),
+                       "exchange": ("none" if not use_dist else
+                                    {"instep": "xgmi one-shot exchange inside the reduction kernel",
+                                     "standalone": "xgmi one-shot exchange + update kernel after the gradient",
+                                     "rccl": "rccl all-reduce + update"}[mode]),
                        "exchange_calibration": calibration, "replicas_identical": replicas_identical},
             "infer_pixels_per_s": round(infer_pps, 1),
             "infer_from_scene_pixels_per_s": round(infer_scene_pps, 1),
