@@ -29,6 +29,8 @@
 #include <string>
 #include <vector>
 
+#include <unistd.h>
+
 #include "../../include/ccnn.h"
 #include "matio.h"
 
@@ -297,7 +299,16 @@ double run(const Options &opt, const Variant &v, const matio::Array &scene_a, co
             CK(ccnn_comm_connect_local(xch[k], xch.data()));
         }
     } else if (nd > 1) {
-        NCK(ncclCommInitAll(comms.data(), nd, devices.data()));
+        // RCCL prints a version banner on file descriptor 1 when it initialises; stdout belongs to the
+        // reference's own lines (tools/run.sh cuts fields out of them), so the banner goes to stderr
+        fflush(stdout);
+        const int saved_stdout = dup(1);
+        dup2(2, 1);
+        const ncclResult_t init_rc = ncclCommInitAll(comms.data(), nd, devices.data());
+        fflush(stdout);
+        dup2(saved_stdout, 1);
+        close(saved_stdout);
+        NCK(init_rc);
     }
 
     std::vector<double> logloss(300, 0.0);
