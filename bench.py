@@ -353,6 +353,7 @@ def main():
     # the same training steps, one inference pass and one gather of the training list
     roof = None
     kernels = {}
+    fence()   # rank 0 ran the single-GPU extras above: nobody starts exchanging (with bounded waits) before it is back
     if rank == 0:
         L.profile_enable(True)
     psteps = min(args.steps, 300)
