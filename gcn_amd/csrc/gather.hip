@@ -259,6 +259,7 @@ const char *ccnn_error_string(int code)
         case CCNN_E_INVALID: return "ccnn: invalid argument (null pointer, bad size, or band count out of range)";
         case CCNN_E_WORKSPACE: return "ccnn: workspace too small";
         case CCNN_E_RANGE: return "ccnn: size exceeds 32-bit index range";
+        case CCNN_E_SCRATCH: return "ccnn: batch does not fit the library's fixed scratch array (CCNN_NOALLOC_SCRATCH_BYTES)";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "ccnn: unknown error";
     }
 }

@@ -17,6 +17,8 @@
 // A launch boundary costs about as much as one of these kernels' whole run, so the
 // per-sample chain is fused rather than batched layer by layer; FC1 (100 x Pout) is a
 // matrix-vector product per sample here, read through L2.
+#include <mutex>
+
 #include "ccnn_device.h"
 #include "comm.h"
 #include "profile.h"
@@ -714,6 +716,40 @@ int mbgd_impl(const T *params, const T *cubes, const int *onehot, long first, in
 
 using namespace ccnn;
 
+// ---------------------------------------------------------------------------
+// Scratch of the entry point that allocates nothing (ccnn_mbgd_step_noalloc_f32): the
+// per-sample rows the two training kernels hand to each other (pool, a1, delta1, delta2,
+// conv-gradient tiles), which every other entry point takes from a caller-owned workspace.
+// Every device that loads this library holds its own copy of the array, at its own address,
+// until the process ends.  Host code must never pass the array's NAME to a kernel or a memset
+// (on the host it is a stand-in, not a device address): scratch_on_current_device() resolves
+// the address once per device and everything else uses that pointer.
+static __device__ __align__(256) unsigned char scratch[CCNN_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+constexpr int SCRATCH_MAX_DEVICES = 64;
+std::mutex g_scratch_mu;
+void *g_scratch_ptr[SCRATCH_MAX_DEVICES];   // [device] -> address of that device's copy of `scratch`
+
+int scratch_on_current_device(void **out)
+{
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= SCRATCH_MAX_DEVICES) return CCNN_E_RANGE;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void *p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));   // the current device's copy
+        if (e != hipSuccess) return (int)e;
+        if (!p) return (int)hipErrorInvalidSymbol;
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+}  // namespace
+
 #ifdef CCNN_FB_TIMING
 extern "C" int ccnn_debug_fb_ticks(unsigned long long *out)
 {
@@ -757,6 +793,23 @@ int ccnn_mbgd_step_f32(float *params, const float *cubes, const int *onehot, lon
     UpdateRule<float> upd{params, lr, 0, d.off_b0, d.off_w1};
     return mbgd_impl<float, true>(params, cubes, onehot, first, B, z, nullptr, upd, loss_values, nullptr,
                                   workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int ccnn_mbgd_step_noalloc_f32(float *params, const float *cubes, const int *onehot, long first, int B, int z,
+                               float lr, double *loss_values, void *stream)
+{
+    ccnn_dims_t d;
+    if (make_dims(z, &d) || !params || B <= 0) return CCNN_E_INVALID;
+    if (MbgdWs<float>::bytes(B, d) > (size_t)CCNN_NOALLOC_SCRATCH_BYTES) return CCNN_E_SCRATCH;
+    void *ws = nullptr;
+    if (int e = scratch_on_current_device(&ws)) return e;
+    // every row of the scratch a step reads is written by the same step first (pool, a1, d1, d2 and
+    // the conv-gradient tiles by sample_fwd_bwd, for exactly the B rows grad_reduce then sums), so
+    // nothing has to be cleared between calls; what an earlier, larger call left beyond row B is
+    // never read
+    UpdateRule<float> upd{params, lr, 0, d.off_b0, d.off_w1};
+    return mbgd_impl<float, true>(params, cubes, onehot, first, B, z, nullptr, upd, loss_values, nullptr, ws,
+                                  (size_t)CCNN_NOALLOC_SCRATCH_BYTES, (hipStream_t)stream);
 }
 
 int ccnn_mbgd_step_f64(double *params, const double *cubes, const int *onehot, long first, int B, int z,

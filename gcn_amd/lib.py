@@ -43,6 +43,7 @@ _SIG = {
     "ccnn_mbgd_grad_f32": (C.c_int, [_P, _P, _P, C.c_long, C.c_int, C.c_int, _P, _P, _P, _P, C.c_size_t, _P]),
     "ccnn_mbgd_grad_f64": (C.c_int, [_P, _P, _P, C.c_long, C.c_int, C.c_int, _P, _P, _P, _P, C.c_size_t, _P]),
     "ccnn_mbgd_step_f32": (C.c_int, [_P, _P, _P, C.c_long, C.c_int, C.c_int, C.c_float, _P, _P, C.c_size_t, _P]),
+    "ccnn_mbgd_step_noalloc_f32": (C.c_int, [_P, _P, _P, C.c_long, C.c_int, C.c_int, C.c_float, _P, _P]),
     "ccnn_mbgd_step_f64": (C.c_int, [_P, _P, _P, C.c_long, C.c_int, C.c_int, C.c_double, _P, _P, C.c_size_t, _P]),
     "ccnn_update_f64": (C.c_int, [_P, _P, C.c_double, C.c_int, C.c_long, _P]),
     "ccnn_update_f32": (C.c_int, [_P, _P, C.c_float, C.c_int, C.c_int, _P]),

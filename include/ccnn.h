@@ -53,6 +53,7 @@ extern "C" {
 #define CCNN_E_INVALID (-1)   /* null pointer, non-positive size, z out of range */
 #define CCNN_E_WORKSPACE (-2) /* workspace smaller than ccnn_*_workspace_bytes() */
 #define CCNN_E_RANGE (-3)     /* a size exceeds what the kernels index with int32 */
+#define CCNN_E_SCRATCH (-4)   /* the batch needs more than CCNN_NOALLOC_SCRATCH_BYTES of scratch */
 
 #define CCNN_MIN_BANDS 21    /* at least one convolution output */
 #define CCNN_MAX_BANDS 448     /* whole cube + filters stay under 64 KB of LDS in fp64 */
@@ -151,6 +152,23 @@ int ccnn_mbgd_step_f32(float *params, const float *cubes, const int *onehot, lon
 int ccnn_mbgd_step_f64(double *params, const double *cubes, const int *onehot, long first, int B,
                        int z, double lr, double *loss_values, void *workspace,
                        size_t workspace_bytes, void *stream);
+
+/* ccnn_mbgd_step_f32 without a workspace argument and without any allocation.  No
+ * counterpart in the reference: it is for callers that cannot allocate device memory or
+ * pass a workspace along -- code under HIP graph capture, tight serving/training loops,
+ * harnesses that forbid hipMalloc.  The per-sample rows the step's two kernels hand to
+ * each other live in a fixed device array inside the library, CCNN_NOALLOC_SCRATCH_BYTES
+ * per GPU, held until the process ends; a batch whose rows
+ * (ccnn_mbgd_workspace_bytes(B, z, 4)) do not fit is rejected with CCNN_E_SCRATCH: 8 MiB
+ * holds B = 513 at z = 103, 457 at z = 200, 359 at z = 448.  The call makes no hipMalloc /
+ * hipFree and uses no allocating library routine (keep ccnn_profile_enable off: the timing
+ * hooks create events).  Results are bit-identical to ccnn_mbgd_step_f32.  All calls on one
+ * GPU share that GPU's array: calls that overlap in time on one GPU (two streams, two
+ * threads) race; calls ordered by one stream are safe, and nothing has to be cleared
+ * between them. */
+#define CCNN_NOALLOC_SCRATCH_BYTES (8 << 20)
+int ccnn_mbgd_step_noalloc_f32(float *params, const float *cubes, const int *onehot, long first,
+                               int B, int z, float lr, double *loss_values, void *stream);
 
 /* Parameter update from a summed gradient.  Replaces update_params_row x2 +
  * update_params_col (gcn_mbgd_fp64.cu:500-557, 1034-1060) and, on several GPUs,

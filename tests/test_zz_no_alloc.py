@@ -1,0 +1,77 @@
+"""GPU: the entry point that allocates nothing (ccnn_mbgd_step_noalloc_f32, its per-sample rows
+in a fixed device array of the library) against ccnn_mbgd_step_f32 with a caller-owned
+workspace, through the C ABI: two calls in a row, the second with a smaller batch, must leave
+bit-identical parameters and losses; a batch beyond the fixed array is rejected."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as orc
+from gcn_amd import lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def test_noalloc_step_equals_workspace_step_twice_second_smaller():
+    lib = L.load()
+    z = 103
+    d = L.dims(z)
+    rng = np.random.default_rng(5)
+    n = 200
+    cubes = torch.from_numpy(rng.random((n, 9 * z)).astype(np.float32)).cuda()
+    onehot_h = np.zeros((n, 13), dtype=np.int32)
+    onehot_h[np.arange(n), rng.integers(0, 13, n)] = 1
+    onehot = torch.from_numpy(onehot_h).cuda()
+    orc.srand(5)
+    p0 = orc.init_params_f32(z)
+    p_ws, p_na = torch.from_numpy(p0).cuda(), torch.from_numpy(p0).cuda()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # inputs and outputs exist before the calls under test; from here on nothing is allocated for the no-alloc calls
+    l_ws = torch.zeros(128, dtype=torch.float64, device="cuda")
+    l_na = torch.zeros(128, dtype=torch.float64, device="cuda")
+    ws_bytes = lib.ccnn_mbgd_workspace_bytes(128, z, 4)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for first, B in ((0, 128), (128, 37)):          # the second call is smaller: rows 37..127 of the scratch are stale
+        mem_before = torch.cuda.memory_allocated()
+        L.check(lib.ccnn_mbgd_step_noalloc_f32(_p(p_na), _p(cubes), _p(onehot), first, B, z, 0.04, _p(l_na), st),
+                "ccnn_mbgd_step_noalloc_f32")
+        assert torch.cuda.memory_allocated() == mem_before
+        L.check(lib.ccnn_mbgd_step_f32(_p(p_ws), _p(cubes), _p(onehot), first, B, z, 0.04, _p(l_ws), _p(ws),
+                                       ws.numel(), st), "ccnn_mbgd_step_f32")
+        torch.cuda.synchronize()
+        assert torch.equal(p_na, p_ws), (first, B)
+        assert torch.equal(l_na[:B], l_ws[:B]), (first, B)
+    assert not torch.equal(p_na, torch.from_numpy(p0).cuda())      # the steps did move the weights
+    # and the pair agrees with the oracle to the fp32 bar
+    p_ref = p0.copy()
+    cubes_h = cubes.cpu().numpy()
+    for first, B in ((0, 128), (128, 37)):
+        orc.mbgd_step(p_ref, cubes_h, onehot_h, first, B, z, np.float32(0.04), want_grad=False)
+    out = p_na.cpu().numpy()
+    for lo, hi in ((0, d.off_b0), (d.off_w1, d.off_b1), (d.off_b1, d.off_w2), (d.off_w2, d.off_b2),
+                   (d.off_b2, d.nparams)):
+        assert np.abs(out[lo:hi] - p_ref[lo:hi]).max() <= 1e-5 * np.abs(p_ref[lo:hi]).max(), (lo, hi)
+
+
+def test_noalloc_step_rejects_batches_beyond_the_fixed_array():
+    lib = L.load()
+    z = 448
+    B = 400                                          # 8 MiB holds 359 samples' rows at z = 448
+    assert lib.ccnn_mbgd_workspace_bytes(B, z, 4) > (8 << 20)
+    d = L.dims(z)
+    params = torch.zeros(d.nparams, dtype=torch.float32, device="cuda")
+    cubes = torch.zeros((B, 9 * z), dtype=torch.float32, device="cuda")
+    onehot = torch.zeros((B, 13), dtype=torch.int32, device="cuda")
+    loss = torch.zeros(B, dtype=torch.float64, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib.ccnn_mbgd_step_noalloc_f32(_p(params), _p(cubes), _p(onehot), 0, B, z, 0.04, _p(loss), st)
+    assert rc == -4 and "scratch" in L.error_string(rc)
+    torch.cuda.synchronize()
+    assert float(params.abs().max()) == 0.0          # nothing ran
