@@ -405,6 +405,20 @@ double run(const Options &opt, const Variant &v, const matio::Array &scene_a, co
                 }
                 single_rate = (v.f32 ? (double)loss32 : loss64) / s.n_train;
                 if (iter < 300) logloss[iter] = single_rate;
+                if (oneshot) {
+                    // a wait that ran out inside the exchange leaves the parameters at the last completed
+                    // step and raises the status word: stop instead of training on
+                    for (int k = 0; k < nd; k++) {
+                        int st = 0;
+                        CK(hipSetDevice(dev[k].id));
+                        CK(ccnn_comm_status(xch[k], &st));
+                        if (st) {
+                            fprintf(stderr, "%s:%d: device %d gave up waiting for a peer inside the gradient exchange (epoch %d)\n",
+                                    __FILE__, __LINE__, dev[k].id, iter + 1);
+                            exit(EXIT_FAILURE);
+                        }
+                    }
+                }
             }
             char str[50];
             snprintf(str, sizeof(str), "%d,", iter + 1);

@@ -43,6 +43,15 @@ class NodeComm:
         if any(codes):
             self._destroy()
             raise _l.CcnnError(next(c for c in codes if c), "ccnn_comm_connect (on some rank)")
+        sh = C.c_int(0)
+        _l.check(lib.ccnn_comm_shares_device(self._h, C.byref(sh)), "ccnn_comm_shares_device")
+        flags = [None] * self.world
+        dist.all_gather_object(flags, bool(sh.value), group=group)
+        # Several ranks on one GPU (tests on a one-GPU box): a kernel that waits for its peers inside
+        # a launch then holds compute units its peers' kernels need.  The step that exchanges inside
+        # its reduction kernel is only safe there while the ranks launch close together; drivers that
+        # cannot promise that (fit_mbgd) take the gradient + stand-alone exchange route instead.
+        self.shared_device = any(flags)
 
     def _destroy(self):
         if getattr(self, "_h", None):
@@ -101,6 +110,11 @@ class NodeComm:
         oh = torch.from_numpy(oh).to(self.device)
         lr = 0.04
         p_dp, p_ref = p0.clone(), p0.clone()
+        # The same step without the exchange first: the one-off costs of a process's first launch of
+        # these kernels (code object load, LDS limit) must not count against the peers' bounded waits.
+        ops.mbgd_step(p0.clone(), cubes, oh, 0, B, z, lr)
+        torch.cuda.synchronize(self.device)
+        dist.barrier(group=self.group)
         ops.mbgd_step(p_dp, cubes, oh, 0, B, z, lr, comm=self, divisor=B * self.world)
         torch.cuda.synchronize(self.device)
         if not self._agree(self.status() == 0):

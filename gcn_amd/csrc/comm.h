@@ -125,10 +125,13 @@ __device__ __forceinline__ void comm_publish(const CommDev &c, int par, unsigned
 }
 
 // Waits until every rank's flag [par][r][part] in the local buffer shows `step`.  All threads
-// call it; afterwards the slots may be read with comm_load.
-__device__ __forceinline__ void comm_wait(const CommDev &c, int par, unsigned step, int part, int tid)
+// call it; afterwards the slots may be read with comm_load.  Returns false -- to every thread of
+// the workgroup alike -- when a wait ran out (status is then set): the slots hold whatever was
+// there before and must not be used.
+__device__ __forceinline__ bool comm_wait(const CommDev &c, int par, unsigned step, int part, int tid)
 {
     char *mine = c.peer[c.rank];
+    int gave_up = 0;
     if (tid < c.world) {
         unsigned *status = reinterpret_cast<unsigned *>(mine + c.status_off);
         const unsigned *flag = reinterpret_cast<const unsigned *>(mine + c.flags_off) +
@@ -142,12 +145,14 @@ __device__ __forceinline__ void comm_wait(const CommDev &c, int par, unsigned st
                 (wall_clock64() - t0 > c.spin_ticks ||
                  __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))) {
                 __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                gave_up = 1;
                 break;
             }
         }
     }
-    __syncthreads();
+    const bool ok = !__syncthreads_or(gave_up);
     __atomic_thread_fence(__ATOMIC_ACQUIRE);   // system scope: nothing below is served from a stale cache
+    return ok;
 }
 #endif
 
@@ -158,16 +163,17 @@ struct ccnn_comm {
     int device;
     long max_elems;
     int elem;
-    size_t total_bytes;   // bytes of the layout
-    size_t alloc_bytes;   // bytes of the allocation behind it (a pooled buffer may be larger)
+    size_t total_bytes;   // bytes of the exchange buffer
+    unsigned long long identity;   // PCI identity of this rank's GPU
+    bool shared_device;   // some peer rank runs on this rank's own GPU (known after connect)
     bool opened[ccnn::COMM_MAX_RANKS];
     unsigned step;
     unsigned nonce;   // drawn at creation; the ranks' nonces together seed the sequence numbers
     // Sequence number and parity of the next call (all ranks issue the same calls in the same
     // order).  Numbering starts at a value derived from every rank's nonce, so the numbers of one
-    // set of buffers are not those of the previous set: exchange buffers are recycled within a
-    // process, and a leftover word that carried a number that is expected again would be taken
-    // for current if the clearing of the recycled buffer were ever reordered after a peer's store.
+    // set of buffers are not those of the previous set: a later allocation may get the same
+    // memory back, and a leftover word that carried a number that is expected again would be
+    // taken for current if the clearing of the new buffer were ever reordered after a peer's store.
     unsigned next_step()
     {
         step++;

@@ -20,10 +20,8 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
-#include <mutex>
 #include <new>
 #include <random>
-#include <vector>
 
 #include "comm.h"
 #include "profile.h"
@@ -83,7 +81,9 @@ __global__ __launch_bounds__(256) void allreduce_apply(T *target, const T *src, 
     }
     // 2. publish, 3. wait for every rank's chunk
     comm_publish(c, par, step, chunk, tid);
-    comm_wait(c, par, step, chunk, tid);
+    // a wait that ran out leaves `target` as it was (the status word tells the host): sums of
+    // stale slots are never applied
+    if (!comm_wait(c, par, step, chunk, tid)) return;
     // 4. sum in rank order, apply
     T sum[VW];
 #pragma unroll
@@ -120,18 +120,33 @@ int allreduce_launch(ccnn_comm *cm, T *target, const T *src, long n, Rule rule, 
 using namespace ccnn;
 
 namespace {
-// Exchange buffers are never handed back to the runtime while the process lives: on this
-// stack, once a buffer that peers had mapped is unmapped there AND freed here, the next set of
-// buffers misbehaves (peers' writes land in unrelated allocations of this process: observed as
-// corrupted inputs of the first step after re-creating the buffers, 100 % reproducible with 4
-// ranks).  Keeping the allocation avoids it, so destroyed buffers wait here for the next create.
-struct PooledBuffer {
-    void *ptr;
-    size_t bytes;
-    int device;
-};
-std::mutex g_pool_mu;
-std::vector<PooledBuffer> g_pool;
+// CCNN_COMM_DEBUG=1: one line per buffer event on stderr (owner address, IPC handle bytes, the
+// address a peer's handle was mapped at, return codes of unmap and free).
+bool comm_debug()
+{
+    static const bool on = getenv("CCNN_COMM_DEBUG") != nullptr;
+    return on;
+}
+// Identity of the physical device behind the current HIP device (ranks may address one GPU under
+// different ordinals): PCI domain, bus and device number.
+unsigned long long device_identity(int device)
+{
+    int dom = 0, bus = 0, dv = 0;
+    if (hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, device) != hipSuccess) dom = 0;
+    if (hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, device) != hipSuccess) bus = 0;
+    if (hipDeviceGetAttribute(&dv, hipDeviceAttributePciDeviceId, device) != hipSuccess) dv = 0;
+    (void)hipGetLastError();
+    return ((unsigned long long)(unsigned)dom << 32) | ((unsigned long long)(bus & 0xffff) << 16) | (unsigned)(dv & 0xffff) | (1ull << 63);
+}
+void log_handle(const char *what, int rank, int peer, const void *ptr, const void *handle, int rc)
+{
+    if (!comm_debug()) return;
+    char hex[2 * CCNN_COMM_HANDLE_BYTES + 1] = {0};
+    if (handle)
+        for (int i = 0; i < CCNN_COMM_HANDLE_BYTES; i++)
+            snprintf(hex + 2 * i, 3, "%02x", static_cast<const unsigned char *>(handle)[i]);
+    fprintf(stderr, "[ccnn-comm rank %d] %s peer=%d ptr=%p rc=%d handle=%s\n", rank, what, peer, ptr, rc, hex);
+}
 
 }  // namespace
 
@@ -171,20 +186,9 @@ int ccnn_comm_create(int world, int rank, long max_elems, int elem_size, ccnn_co
     }
     hipError_t e = hipGetDevice(&cm->device);
     void *buf = nullptr;
-    cm->alloc_bytes = cm->total_bytes;
-    if (e == hipSuccess) {
-        std::lock_guard<std::mutex> lk(g_pool_mu);
-        for (size_t i = 0; i < g_pool.size(); i++) {
-            if (g_pool[i].device == cm->device && g_pool[i].bytes >= cm->total_bytes) {
-                buf = g_pool[i].ptr;
-                cm->alloc_bytes = g_pool[i].bytes;
-                g_pool.erase(g_pool.begin() + i);
-                break;
-            }
-        }
-    }
+    cm->shared_device = false;
     // uncached: peers write it over xGMI behind the local L2's back
-    if (e == hipSuccess && !buf) e = hipExtMallocWithFlags(&buf, cm->total_bytes, hipDeviceMallocUncached);
+    if (e == hipSuccess) e = hipExtMallocWithFlags(&buf, cm->total_bytes, hipDeviceMallocUncached);
     if (e == hipSuccess) e = hipMemset(buf, 0, cm->total_bytes);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) {
@@ -193,12 +197,14 @@ int ccnn_comm_create(int world, int rank, long max_elems, int elem_size, ccnn_co
                     (unsigned)(reinterpret_cast<uintptr_t>(cm) >> 4);
         e = hipMemcpy(static_cast<char *>(buf) + d.status_off + 8, &cm->nonce, sizeof(unsigned), hipMemcpyHostToDevice);
     }
+    if (e == hipSuccess) {
+        cm->identity = device_identity(cm->device);
+        e = hipMemcpy(static_cast<char *>(buf) + d.status_off + 16, &cm->identity, sizeof(cm->identity), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t *>(handle), buf);
+    log_handle("create", rank, rank, buf, handle, (int)e);
     if (e != hipSuccess) {
-        if (buf) {
-            std::lock_guard<std::mutex> lk(g_pool_mu);
-            g_pool.push_back({buf, cm->alloc_bytes, cm->device});
-        }
+        if (buf) (void)hipFree(buf);
         delete cm;
         return (int)e;
     }
@@ -215,18 +221,23 @@ int ccnn_comm_connect(ccnn_comm_t *cm, const void *handles)
         if (r == cm->dev.rank || cm->dev.peer[r]) continue;
         void *p = nullptr;
         hipError_t e = hipIpcOpenMemHandle(&p, h[r], hipIpcMemLazyEnablePeerAccess);
+        log_handle("open", cm->dev.rank, r, p, &h[r], (int)e);
         if (e != hipSuccess) return (int)e;
         cm->dev.peer[r] = static_cast<char *>(p);
         cm->opened[r] = true;
     }
-    // every rank wrote its nonce before it published its handle: combine them into the first
-    // sequence number (the same on every rank)
+    // every rank wrote its nonce and its device's identity before it published its handle:
+    // combine the nonces into the first sequence number (the same on every rank), and note
+    // whether a peer sits on this rank's own GPU
     unsigned seed = 0;
     for (int r = 0; r < cm->dev.world; r++) {
         unsigned v = 0;
+        unsigned long long id = 0;
         hipError_t e = hipMemcpy(&v, cm->dev.peer[r] + cm->dev.status_off + 8, sizeof(v), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(&id, cm->dev.peer[r] + cm->dev.status_off + 16, sizeof(id), hipMemcpyDeviceToHost);
         if (e != hipSuccess) return (int)e;
         seed = seed * 2654435761u + v;
+        if (r != cm->dev.rank && id == cm->identity) cm->shared_device = true;
     }
     cm->step = seed | 1u;
     return 0;
@@ -246,10 +257,18 @@ int ccnn_comm_connect_local(ccnn_comm_t *cm, ccnn_comm_t *const *peers)
             (void)hipGetLastError();
         }
         cm->dev.peer[r] = peers[r]->dev.peer[r];
+        if (peers[r]->identity == cm->identity) cm->shared_device = true;
     }
     unsigned seed = 0;
     for (int r = 0; r < cm->dev.world; r++) seed = seed * 2654435761u + (r == cm->dev.rank ? cm->nonce : peers[r]->nonce);
     cm->step = seed | 1u;
+    return 0;
+}
+
+int ccnn_comm_shares_device(ccnn_comm_t *cm, int *shared)
+{
+    if (!cm || !shared) return CCNN_E_INVALID;
+    *shared = cm->shared_device ? 1 : 0;
     return 0;
 }
 
@@ -266,25 +285,32 @@ int ccnn_comm_status(ccnn_comm_t *cm, int *status)
 int ccnn_comm_disconnect(ccnn_comm_t *cm)
 {
     if (!cm) return CCNN_E_INVALID;
+    int first_error = 0;
     for (int r = 0; r < cm->dev.world; r++) {
         if (r == cm->dev.rank) continue;
-        if (cm->opened[r]) (void)hipIpcCloseMemHandle(cm->dev.peer[r]);
+        if (cm->opened[r]) {
+            const hipError_t e = hipIpcCloseMemHandle(cm->dev.peer[r]);
+            log_handle("close", cm->dev.rank, r, cm->dev.peer[r], nullptr, (int)e);
+            if (e != hipSuccess && !first_error) first_error = (int)e;   // a mapping that stays open must not go unnoticed
+        }
         cm->opened[r] = false;
         cm->dev.peer[r] = nullptr;
     }
-    return 0;
+    return first_error;
 }
 
 int ccnn_comm_destroy(ccnn_comm_t *cm)
 {
     if (!cm) return 0;
-    (void)ccnn_comm_disconnect(cm);
+    const int rc = ccnn_comm_disconnect(cm);
+    int rc_free = 0;
     if (cm->dev.peer[cm->dev.rank]) {
-        std::lock_guard<std::mutex> lk(g_pool_mu);
-        g_pool.push_back({cm->dev.peer[cm->dev.rank], cm->alloc_bytes, cm->device});
+        const hipError_t e = hipFree(cm->dev.peer[cm->dev.rank]);
+        log_handle("free", cm->dev.rank, cm->dev.rank, cm->dev.peer[cm->dev.rank], nullptr, (int)e);
+        rc_free = (int)e;
     }
     delete cm;
-    return 0;
+    return rc ? rc : rc_free;
 }
 
 int ccnn_allreduce_f32(ccnn_comm_t *cm, float *buf, long n, void *stream)

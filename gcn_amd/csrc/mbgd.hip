@@ -497,7 +497,7 @@ __device__ __forceinline__ T colsum8(int B, int rg, int c, T *red, Term term)
 // raises its flag there, waits for the same workgroup of every rank and adds the world
 // contributions in rank order before `upd` sees them (comm.h).  No grid-wide barrier: a
 // workgroup only depends on its namesakes on the other ranks.
-template <typename T>
+template <typename T, int KF>
 __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int off_w1, int off_b1,
                                                           int off_w2, int off_b2,
                                                           const T *__restrict__ pool,
@@ -523,11 +523,11 @@ __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int o
             const T *bp = d1 + min(n0 + col, H - 1);
             typename Mma<T>::acc_t acc = {0, 0, 0, 0};
             const int ks = (B + 3) >> 2;
-            // k-steps of operands in flight: fp32 takes a batch of 128 in one memory round trip
-            // (16 -> 32: step 24.6 -> 23.3 us).  fp64 stays at 16 so that the kernel keeps within 128
-            // registers and two workgroups fit a CU: ranks that share one GPU (the multi-process
-            // tests) wait for each other inside this kernel, so all of them must be resident at once.
-            constexpr int KF = sizeof(T) == 4 ? 32 : 16;
+            // KF k-steps of operands in flight: 32 takes a batch of 128 in one memory round trip
+            // (16 -> 32 in fp32: step 24.6 -> 23.3 us).  The fp64 kernel with 16 keeps within 128
+            // registers, so that two workgroups fit a CU: the host picks that form only for ranks
+            // that share one GPU, which wait for each other inside this kernel and must all be
+            // resident at once.
             for (int s = 0; s < ks; s += KF) {
                 T a[KF], w[KF];
 #pragma unroll
@@ -584,6 +584,7 @@ __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int o
             }
         }
     }
+    int gave_up = 0;
     if (xc.world > 0) {
         // The outputs travel in launch geometry, not in parameter order (a dW1 workgroup's slot
         // region holds four values per thread, the others one value per lane of their first wave),
@@ -624,7 +625,8 @@ __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int o
                 unsigned in[4 * WPV];
 #pragma unroll
                 for (int h = 0; h < WPV; h++)
-                    comm_load_tagged(src + 4 * h, in + 4 * h, max(min(nv * WPV - 4 * h, 4), 0), xstep, xc);
+                    if (!comm_load_tagged(src + 4 * h, in + 4 * h, max(min(nv * WPV - 4 * h, 4), 0), xstep, xc)) gave_up = 1;
+                if (gave_up) break;   // in[] is not set: nothing of this step may reach the parameters
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     if (j < nv) {
@@ -638,6 +640,11 @@ __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int o
                 }
             }
         }
+        // A wait that ran out (peer gone or stalled; the status word is set): the whole workgroup
+        // leaves its parameters at the last completed step.  Once one workgroup has given up the
+        // others see the status word within a thousand polls and give up too, so a peer that never
+        // launched leaves every parameter untouched.
+        if (__syncthreads_or(gave_up)) return;
     }
 #pragma unroll
     for (int j = 0; j < 4; j++)
@@ -705,8 +712,10 @@ int mbgd_impl(const T *params, const T *cubes, const int *onehot, long first, in
         xstep = cm->next_step();
     }
     {
-        launch("grad_reduce", grad_reduce<T>, dim3(nblocks), dim3(GR_THREADS), 0, st, B, d.pout, d.off_w1, d.off_b1,
-               d.off_w2, d.off_b2, w.pool, w.a1, w.d1, w.d2, w.slab, nb_w1, nb_w0, nb_w2, grad, upd, xc, xstep);
+        const bool narrow = sizeof(T) == 8 && cm && cm->shared_device;
+        launch("grad_reduce", narrow ? grad_reduce<T, 16> : grad_reduce<T, 32>, dim3(nblocks), dim3(GR_THREADS), 0, st, B,
+               d.pout, d.off_w1, d.off_b1, d.off_w2, d.off_b2, w.pool, w.a1, w.d1, w.d2, w.slab, nb_w1, nb_w0, nb_w2,
+               grad, upd, xc, xstep);
     }
     CCNN_LAUNCH_CHECK();
     return 0;

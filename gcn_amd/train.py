@@ -157,12 +157,23 @@ def fit_mbgd(params, cubes, onehot, z, batch=100, lr=None, min_err=None, max_ite
         for i0, (first, nb) in enumerate(steps):
             if comm.world == 1 and stepper is None:
                 st.step_fused(first, nb, lr, loss_d[i0])
-            elif node is not None:
+            elif node is not None and not node.shared_device:
                 ops.mbgd_step(params, cubes, onehot, first, nb, z, lr, loss_values=loss_d[i0], workspace=st.ws,
                               comm=node, divisor=batch)
+            elif node is not None:
+                # ranks that share a GPU: gradient first (waits for nobody), then the stand-alone
+                # exchange + update kernel, which is small enough to leave room for the peers' work
+                node.allreduce_update(params, st.grad(first, nb, loss_d[i0]), lr, z, divisor=batch)
             else:
                 g = comm.all_reduce(st.grad(first, nb, loss_d[i0]))
                 st.update(g, lr, batch if nb == sub_b else nb)
+        if node is not None:
+            # a wait that ran out inside the exchange left the parameters at the last completed
+            # step (the kernels never apply a partial sum); no rank may train on from there
+            bad = torch.tensor([node.status()], dtype=torch.float64, device=params.device)
+            if comm.all_reduce(bad).item() != 0:
+                raise RuntimeError(f"epoch {it}: a rank gave up waiting for a peer inside the gradient exchange "
+                                   "(ccnn_comm_status != 0); parameters are those of the last completed step")
         # one D2H per epoch; the host adds the per-sample losses in sample order
         lv_all = loss_d[:len(steps)].cpu().numpy()
         lv = np.concatenate([lv_all[i, :nb] for i, (_, nb) in enumerate(steps)]) if steps else lv_all.ravel()[:0]

@@ -265,7 +265,9 @@ int ccnn_host_partition(long n_train, int batch, int n_ranks, int rank, long ste
  * other ranks' comm objects to ccnn_comm_connect_local (all GPUs in one process).
  * Collective calls must be issued by all ranks in the same order; on one rank they
  * are ordered by the stream.  At most 16 ranks.  ccnn_comm_status synchronises and
- * reports 1 if a rank ever gave up waiting for a peer (peer process gone). */
+ * reports 1 if a rank ever gave up waiting for a peer (peer process gone or stalled).  A
+ * call whose wait ran out applies NOTHING: the parameters (or the buffer) stay as the last
+ * completed call left them, and every later call on that comm gives up at once. */
 #define CCNN_COMM_HANDLE_BYTES 64
 typedef struct ccnn_comm ccnn_comm_t;
 int ccnn_comm_create(int world, int rank, long max_elems, int elem_size, ccnn_comm_t **comm,
@@ -273,10 +275,16 @@ int ccnn_comm_create(int world, int rank, long max_elems, int elem_size, ccnn_co
 int ccnn_comm_connect(ccnn_comm_t *comm, const void *handles);
 int ccnn_comm_connect_local(ccnn_comm_t *comm, ccnn_comm_t *const *peers);
 int ccnn_comm_status(ccnn_comm_t *comm, int *status);
+/* *shared = 1 if, after connect, some peer rank turned out to run on this rank's own GPU
+ * (several processes on one card).  Kernels that wait for their peers inside a launch then
+ * compete with those peers for the same compute units: a caller should keep such ranks'
+ * launches close together or use ccnn_mbgd_grad_* + ccnn_allreduce_update_* (whose waiting
+ * kernel leaves room for the peers' work).  No counterpart in the reference. */
+int ccnn_comm_shares_device(ccnn_comm_t *comm, int *shared);
 /* Tear-down is two-phase across ranks: every rank first unmaps its peers' buffers
- * (ccnn_comm_disconnect), and only when ALL ranks have done so may any rank free its own
- * (ccnn_comm_destroy; it disconnects first if that was not done).  The buffer itself goes to a
- * process-wide pool for the next ccnn_comm_create instead of back to the runtime. */
+ * (ccnn_comm_disconnect; returns the first unmap error, if any), and only when ALL ranks
+ * have done so may any rank free its own (ccnn_comm_destroy; it disconnects first if that
+ * was not done). */
 int ccnn_comm_disconnect(ccnn_comm_t *comm);
 int ccnn_comm_destroy(ccnn_comm_t *comm);
 /* buf[k] = sum over ranks of buf[k], in place. */

@@ -46,11 +46,59 @@ def fit(rank, world, dev):
     assert all(torch.equal(every[0], e) for e in every)
 
 
+def stalled_peer(rank, world, dev):
+    """Rank 1 never launches its step: rank 0's waits run out (CCNN_COMM_WAIT_MS), its parameters
+    must stay bit for bit what they were, and the status word must say so - for the step that
+    exchanges inside its reduction kernel and for the stand-alone exchange + update."""
+    z = 60
+    d = L.dims(z)
+    for dtype in (torch.float32, torch.float64):
+        comm = NodeComm(d.nparams, dtype)
+        rng = np.random.default_rng(3)
+        p0 = torch.from_numpy((rng.random(d.nparams) - 0.5) / 10).to(dtype).to(dev)
+        B = 6
+        cubes = torch.from_numpy(rng.random((B, 9 * z))).to(dtype).to(dev)
+        oh = np.zeros((B, 13), dtype=np.int32)
+        oh[np.arange(B), rng.integers(0, 13, B)] = 1
+        oh = torch.from_numpy(oh).to(dev)
+        p = p0.clone()
+        assert comm.status() == 0
+        if rank == 0:
+            ops.mbgd_step(p, cubes, oh, 0, B, z, 0.04, comm=comm, divisor=B * world)
+            torch.cuda.synchronize()
+            assert comm.status() == 1, "the wait ran out but the status word does not say so"
+            assert torch.equal(p, p0), "a timed-out exchange touched the parameters"
+            # every later call gives up at once and leaves the parameters alone as well
+            g = torch.ones_like(p)
+            comm.allreduce_update(p, g, 0.04, z, divisor=B * world)
+            ops.mbgd_step(p, cubes, oh, 0, B, z, 0.04, comm=comm, divisor=B * world)
+            torch.cuda.synchronize()
+            assert torch.equal(p, p0)
+        dist.barrier()
+        comm.close()
+    # the stand-alone exchange on a fresh set of buffers
+    comm = NodeComm(d.nparams, torch.float32)
+    p0 = torch.full((d.nparams,), 0.25, dtype=torch.float32, device=dev)
+    p = p0.clone()
+    if rank == 0:
+        comm.allreduce_update(p, torch.ones_like(p), 0.04, z)
+        torch.cuda.synchronize()
+        assert comm.status() == 1 and torch.equal(p, p0)
+    dist.barrier()
+    comm.close()
+
+
 def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
+    if "--stalled-peer" in sys.argv:
+        stalled_peer(rank, world, dev)
+        if rank == 0:
+            print("STALL-OK", world, flush=True)
+        dist.destroy_process_group()
+        return
     if "--fit" in sys.argv:
         fit(rank, world, dev)
         if rank == 0:
@@ -59,8 +107,8 @@ def main():
         return
     z = 103
     d = L.dims(z)
-    # fp64 first: the fp32 set then reuses the fp64 set's (larger) pooled buffer, so both a fresh
-    # and a recycled exchange buffer are covered; a third set checks a second recycling
+    # three sets of exchange buffers in a row: each set is freed and the next allocated afresh
+    # (possibly over the same memory), so sequence numbers and stale contents are covered
     for dtype in (torch.float64, torch.float32, torch.float64):
         comm = NodeComm(d.nparams, dtype)
         a = torch.ones(8, dtype=dtype, device=dev)
@@ -103,6 +151,10 @@ def main():
         oh[np.arange(B), rng.integers(0, 13, B)] = 1
         oh = torch.from_numpy(oh).to(dev)
         q_fused, q_ref = p0.clone(), p0.clone()
+        # the ranks share one GPU here: a rank whose reduction kernel already waits for its peers
+        # holds compute units the peers' per-sample kernels need, so the ranks must launch together
+        torch.cuda.synchronize()
+        dist.barrier()
         lv1 = ops.mbgd_step(q_fused, cubes, oh, 0, B, z, 0.04, comm=comm, divisor=B * world)
         g_loc, lv2 = ops.mbgd_grad(q_ref, cubes, oh, 0, B, z)
         comm.allreduce_update(q_ref, g_loc, 0.04, z, divisor=B * world)
