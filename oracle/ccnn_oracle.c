@@ -459,7 +459,7 @@ static double loss_sample_f32(const float *p, const int *lab)
 #define MBGD_SAMPLE(T, SFX, FLIP)                                                                   \
     static void mbgd_sample_##SFX(const T *params, const T *cube, const int *lab, int z,            \
                                   const orc_dims_t *d, T *probs, T *d2, T *d1, T *dW0, T *dB0,      \
-                                  T *dW1, T *dW2, T *ws)                                            \
+                                  T *dW1, T *dW2, T *ws, const int *flip, T *a0_out)                \
     {                                                                                               \
         const T *W0 = params + d->off_w0, *b0 = params + d->off_b0;                                 \
         const T *W1 = params + d->off_w1, *b1 = params + d->off_b1;                                 \
@@ -469,6 +469,16 @@ static double loss_sample_f32(const float *p, const int *lab)
         memset(Delta, 0, sizeof(T) * d->pin);                                                       \
         k_convolution_##SFX(cube, W0, b0, a0, z, FLIP);                                             \
         k_maxpooling_##SFX(a0, pool, pidx, d->re, 0);                                               \
+        if (a0_out) memcpy(a0_out, a0, sizeof(T) * d->pin);                                         \
+        if (flip) /* test hook: pooled feature p takes the OTHER member of its pair */              \
+            for (int p = 0; p < d->pout; p++) {                                                     \
+                const int f = p / d->mre, head = (p % d->mre) * ORC_POOL_LEN + f * d->re;           \
+                if (flip[p] && head + 1 < (f + 1) * d->re) {                                        \
+                    const int other = ((int)pidx[p] == head) ? head + 1 : head;                     \
+                    pool[p] = a0[other];                                                            \
+                    pidx[p] = (T)other;                                                             \
+                }                                                                                   \
+            }                                                                                       \
         k_fully_connect_##SFX(pool, W1, b1, a1, d->pout, ORC_HIDDEN, scratch);                      \
         k_output_and_dvalue_##SFX(a1, W2, b2, probs, lab, d2);                                      \
         k_bp_fully_connect_mbgd_##SFX(W2, d2, dW2, a1, d1, ORC_HIDDEN, ORC_CLASSES, scratch);       \
@@ -499,7 +509,7 @@ static void mbgd_slabs_f64(const double *params, const double *cubes, const int 
             double *g = slabs + (size_t)i1 * d->nparams;
             mbgd_sample_f64(params, cubes + (size_t)s * d->cube, onehot + (size_t)s * ORC_CLASSES, z, d,
                             probs + (size_t)i1 * ORC_CLASSES, g + d->off_b2, g + d->off_b1,
-                            g + d->off_w0, g + d->off_b0, g + d->off_w1, g + d->off_w2, ws);
+                            g + d->off_w0, g + d->off_b0, g + d->off_w1, g + d->off_w2, ws, NULL, NULL);
         }
         free(ws);
     }
@@ -534,6 +544,17 @@ void orc_mbgd_step_f64(double *params, const double *cubes, const int *onehot, l
 void orc_mbgd_step_f32(float *params, const float *cubes, const int *onehot, long first, int B,
                        int z, float lr, double *loss_values, float *probs_out, float *grad_sum)
 {
+    orc_mbgd_step_f32_ex(params, cubes, onehot, first, B, z, lr, loss_values, probs_out, grad_sum, NULL, NULL);
+}
+
+/* orc_mbgd_step_f32 with two test hooks: a0_out [B][F*re] receives every sample's conv outputs
+ * (what maxpooling compares), and flip [B][F*mre] != 0 makes that pooled feature take the other
+ * member of its pair -- the step the reference would have taken had the two conv outputs, equal
+ * to within rounding, compared the other way (maxpooling's strict '<', gcn_mbgd_fp32.cu:251-285). */
+void orc_mbgd_step_f32_ex(float *params, const float *cubes, const int *onehot, long first, int B,
+                          int z, float lr, double *loss_values, float *probs_out, float *grad_sum,
+                          const int *flip, float *a0_out)
+{
     orc_dims_t d;
     orc_dims(z, &d);
     float *slabs = (float *)malloc(sizeof(float) * (size_t)B * d.nparams);
@@ -547,7 +568,9 @@ void orc_mbgd_step_f32(float *params, const float *cubes, const int *onehot, lon
             float *g = slabs + (size_t)i1 * d.nparams;
             mbgd_sample_f32(params, cubes + (size_t)s * d.cube, onehot + (size_t)s * ORC_CLASSES, z, &d,
                             probs + (size_t)i1 * ORC_CLASSES, g + d.off_b2, g + d.off_b1,
-                            g + d.off_w0, g + d.off_b0, g + d.off_w1, g + d.off_w2, ws);
+                            g + d.off_w0, g + d.off_b0, g + d.off_w1, g + d.off_w2, ws,
+                            flip ? flip + (size_t)i1 * d.pout : NULL,
+                            a0_out ? a0_out + (size_t)i1 * d.pin : NULL);
         }
         free(ws);
     }

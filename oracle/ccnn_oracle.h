@@ -91,6 +91,11 @@ void orc_mbgd_step_f64(double *params, const double *cubes, const int *onehot, l
                        int z, double lr, double *loss_values, double *probs, double *grad_sum);
 void orc_mbgd_step_f32(float *params, const float *cubes, const int *onehot, long first, int B,
                        int z, float lr, double *loss_values, float *probs, float *grad_sum);
+/* The same step with test hooks: conv outputs of every sample out (a0_out [B][F*re]), and
+ * pooled features whose pair is to be decided the other way (flip [B][F*mre], non-zero). */
+void orc_mbgd_step_f32_ex(float *params, const float *cubes, const int *onehot, long first, int B,
+                          int z, float lr, double *loss_values, float *probs_out, float *grad_sum,
+                          const int *flip, float *a0_out);
 
 /* Multi-GPU master/worker step (hyper_version_mGPU_MBGD.cu:903-904, 923-952,
  * 962-1173) replayed on one host: n_dev devices, sub-batch B/n_dev, device slices

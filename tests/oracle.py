@@ -184,6 +184,21 @@ def mbgd_step(params, cubes, onehot, first, B, z, lr, want_grad=True):
     return loss_values, probs, grad
 
 
+def mbgd_step_f32_ex(params, cubes, onehot, first, B, z, lr, flip=None, want_a0=False):
+    """fp32 step with the test hooks: returns (loss_values, a0 [B, F*re] or None); `flip`
+    int32 [B, F*mre] marks pooled features whose pair is decided the other way."""
+    d = dims(z)
+    loss_values = np.empty(B, dtype=np.float64)
+    a0 = np.empty((B, d.pin), dtype=np.float32) if want_a0 else None
+    if flip is not None:
+        flip = _chk(np.ascontiguousarray(flip, dtype=np.int32), np.int32)
+        assert flip.shape == (B, d.pout)
+    lib().orc_mbgd_step_f32_ex(_p(_chk(params, np.float32), C.c_float), _p(_chk(cubes, np.float32), C.c_float),
+                               _p(_chk(onehot, np.int32), C.c_int), C.c_long(first), B, z, C.c_float(lr),
+                               _p(loss_values, C.c_double), None, None, _p(flip, C.c_int), _p(a0, C.c_float))
+    return loss_values, a0
+
+
 def mgpu_step_f64(params, cubes, onehot, train_size, i0, B, n_dev, z, lr):
     return lib().orc_mgpu_step_f64(_p(_chk(params, np.float64), C.c_double), _p(_chk(cubes, np.float64), C.c_double),
                                    _p(_chk(onehot, np.int32), C.c_int), C.c_long(train_size), C.c_long(i0),

@@ -9,6 +9,7 @@ import pytest
 import torch
 
 import oracle as orc
+import parity
 import synth
 from gcn_amd import ops, prep
 
@@ -212,15 +213,16 @@ def test_mbgd_steps_match_oracle(dtype, z, B, lr):
     p_ref = params.copy()
     p_gpu, c_gpu, o_gpu = dev(params), dev(cubes), dev(onehot)
     ws = ops.Workspace()
+    d = orc.dims(z)
     for i0 in range(steps):
         lv_ref, pr_ref, g_ref = orc.mbgd_step(p_ref, cubes, onehot, i0 * B, B, z, dtype(lr))
         probs = torch.empty((B, 13), dtype=p_gpu.dtype, device="cuda")
         grad, lv = ops.mbgd_grad(p_gpu, c_gpu, o_gpu, i0 * B, B, z, probs=probs, workspace=ws)
-        assert relerr(grad.cpu().numpy(), g_ref) < TOL[dtype], i0
+        parity.assert_groups(grad.cpu().numpy(), g_ref, d, TOL[dtype], f"gradient, step {i0}")
         assert relerr(lv.cpu().numpy(), lv_ref) < TOL[dtype], i0
         assert relerr(probs.cpu().numpy(), pr_ref) < TOL[dtype], i0
         ops.update(p_gpu, grad, lr, z, divisor=B)
-        assert relerr(p_gpu.cpu().numpy(), p_ref) < TOL[dtype], i0
+        parity.assert_groups(p_gpu.cpu().numpy(), p_ref, d, TOL[dtype], f"parameters, step {i0}")
 
 
 @pytest.mark.parametrize("dtype,z,B,lr", [(np.float64, 176, 100, 0.5), (np.float32, 103, 128, 0.04),
@@ -238,7 +240,7 @@ def test_mbgd_fused_step_matches_oracle(dtype, z, B, lr):
         lv = ops.mbgd_step(p_gpu, c_gpu, o_gpu, i0 * B, B, z, lr, workspace=ws)
         assert relerr(lv.cpu().numpy(), lv_ref) < TOL[dtype], i0
         out = p_gpu.cpu().numpy()
-        assert relerr(out, p_ref) < TOL[dtype], i0
+        parity.assert_groups(out, p_ref, d, TOL[dtype], f"parameters, step {i0}")
         if dtype == np.float32:
             assert np.all(out[d.off_b0:d.off_w1] == 0)
 
