@@ -16,6 +16,7 @@
 
 #include "ccnn_device.h"
 #include "profile.h"
+#include "train_fwd.h"
 
 namespace ccnn {
 
@@ -73,17 +74,24 @@ __device__ unsigned long long g_conv_wg[3 * 2048];   // per workgroup: entry, lo
 #define CONV_STAMP(k) do { } while (0)
 #endif
 
+template <typename T>
+__host__ __device__ inline int conv_px_words(int pout) { return (pout + (int)sizeof(T) - 1) / (int)sizeof(T); }
+
 constexpr int CONV_MAXREG = 64;    // cube elements a lane may hold in flight for the next sample
 constexpr int CONV_MAXWAVES = 8;   // waves per workgroup (fewer when the per-wave LDS region is large)
 constexpr int CONV_CTR_STRIDE = 32;   // ints between two work counters (one 128-byte line each)
 
-template <typename T, bool FLIP, int NREG, bool SCENE>
+// TRAIN: also stores, per pooled feature, which member of its pair won (0: position 2m, 1: 2m+1)
+// as one byte in px[row][f*mre + m] - what bp_maxpooling needs to route the delta back
+// (gcn_mbgd_fp64.cu:439-454).
+template <typename T, bool FLIP, int NREG, bool SCENE, bool TRAIN>
 __global__ __launch_bounds__(64 * CONV_MAXWAVES) void conv_pool_fwd(const T *__restrict__ params,
                                                                      const T *__restrict__ cubes, long first,
                                                                      long nrows, int cube_len, int re, int mre,
                                                                      int off_b0, T *__restrict__ pool,
                                                                      const int *__restrict__ idx9, long plane,
-                                                                     int *__restrict__ ctr)
+                                                                     int *__restrict__ ctr,
+                                                                     unsigned char *__restrict__ px)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int sidx_all[CONV_MAXWAVES][2][16];   // SCENE: lists of the sample being loaded / the one after
@@ -96,8 +104,10 @@ __global__ __launch_bounds__(64 * CONV_MAXWAVES) void conv_pool_fwd(const T *__r
     const int pout = F * mre;
     const int cube_pad = conv_cube_pad(re);
     T *wl = reinterpret_cast<T *>(smem);
-    T *cube = wl + WP_LEN + wave * (cube_pad + pout);   // this wave's sample
+    const int pxw = TRAIN ? conv_px_words<T>(pout) : 0;   // elements of T that hold the wave's pout winner bytes
+    T *cube = wl + WP_LEN + wave * (cube_pad + pout + pxw);   // this wave's sample
     T *pl = cube + cube_pad;                            // and its pooled features
+    unsigned char *pxl = reinterpret_cast<unsigned char *>(pl + pout);
     int(*sidx)[16] = sidx_all[wave];
 
     // Work distribution.  Rows [0, 3W) (W = waves of the grid) are fixed: wave g owns g, W + g and
@@ -201,7 +211,10 @@ __global__ __launch_bounds__(64 * CONV_MAXWAVES) void conv_pool_fwd(const T *__r
         if (PREFETCH && r_nxt >= 0) issue(r_nxt, ib);      // next sample's loads fly during the MFMAs
         int inext = 0;
         if (SCENE) inext = load_idx(r_nn);                 // and the list of the sample after it
-        conv_pool_wave<T>(cube, wl, re, bias0, biasx, lane, [&](int f, int m, T v, int) { pl[f * mre + m] = v; });
+        conv_pool_wave<T>(cube, wl, re, bias0, biasx, lane, [&](int f, int m, T v, int bt) {
+            pl[f * mre + m] = v;
+            if (TRAIN) pxl[f * mre + m] = (unsigned char)(bt - 2 * m);
+        });
         wave_sync();                                       // pooled values complete, cube no longer read
         if (SCENE) {
             ib ^= 1;                                       // the list issue(r_nxt) used is dead: reuse its slot
@@ -218,6 +231,11 @@ __global__ __launch_bounds__(64 * CONV_MAXWAVES) void conv_pool_fwd(const T *__r
             const V *src = reinterpret_cast<const V *>(pl);
             V *dv = reinterpret_cast<V *>(dst);
             for (int o = lane; o < pout / VW; o += 64) dv[o] = src[o];   // pout = 20 mre: whole 16-byte vectors
+            if (TRAIN) {   // pout is a multiple of 4: whole 32-bit words
+                const unsigned *ps = reinterpret_cast<const unsigned *>(pxl);
+                unsigned *pd = reinterpret_cast<unsigned *>(px + row * pout);
+                for (int o = lane; o < pout / 4; o += 64) pd[o] = ps[o];
+            }
         }
         wave_sync();                                       // next cube and list in place, pl free again
         long r_new = -1;
@@ -233,9 +251,9 @@ __global__ __launch_bounds__(64 * CONV_MAXWAVES) void conv_pool_fwd(const T *__r
 }
 
 template <typename T>
-size_t conv_smem(const ccnn_dims_t &d, int nwaves)
+size_t conv_smem(const ccnn_dims_t &d, int nwaves, bool train = false)
 {
-    return (size_t)(WP_LEN + nwaves * (conv_cube_pad(d.re) + d.pout)) * sizeof(T);
+    return (size_t)(WP_LEN + nwaves * (conv_cube_pad(d.re) + d.pout + (train ? conv_px_words<T>(d.pout) : 0))) * sizeof(T);
 }
 
 // ---------------------------------------------------------------------------
@@ -277,11 +295,23 @@ extern "C" int ccnn_debug_fc_wg(unsigned long long *out)
 #define FC_STAMP(k) do { } while (0)
 #endif
 
-template <typename T, int MS>
+// TRAIN (the minibatch step's forward half): the epilogue goes on to what output_and_dvalue and the
+// first bp_fully_connect produce per sample (gcn_mbgd_fp64.cu:307-354, 401-436) - a1, delta2 =
+// (p - y)/13, delta1 = (13-wide tree of W2 delta2)(1 + a1)(1 - a1) - and to loss_function's
+// value (:559-596); `tr` carries the labels and the outputs, all indexed like pool's rows.
+template <typename T>
+struct FcTrainOut {
+    const int *onehot;    // [nrows][13]
+    T *a1, *d1, *d2;      // [nrows][100], [nrows][100], [nrows][13]
+    double *loss_values;  // [nrows]
+};
+
+template <typename T, int MS, bool TRAIN>
 __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params, int off_w1, int off_b1,
                                                    int off_w2, int off_b2, const T *__restrict__ pool,
                                                    int nrows, int pout, T *__restrict__ probs,
-                                                   int *__restrict__ argmax, int *__restrict__ ctr)
+                                                   int *__restrict__ argmax, int *__restrict__ ctr,
+                                                   FcTrainOut<T> tr)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_next;   // the workgroup's next tile, grabbed one tile ahead
@@ -414,6 +444,12 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
         nb = min(MS, nrows - r0);
         issue(0);
     }
+    int lab0 = 0, lab1 = 0;
+    if (TRAIN) {   // this thread's two labels (clamped, unconditional): in flight during the activations
+        const int sl = min(tid >> 3, nb_done - 1), jl = tid & 7;
+        lab0 = tr.onehot[(long)(r0_done + sl) * O + jl];
+        lab1 = tr.onehot[(long)(r0_done + sl) * O + min(jl + 8, O - 1)];
+    }
     T *z1s = wl;
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
@@ -466,6 +502,40 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
                 idx = i;
             }
         argmax[r0_done + s] = idx;
+    }
+    if (TRAIN) {
+        T *d2s = es;   // the exponentials are dead (every lane holds its probabilities in registers)
+        const bool live = has_s && s < nb_done;
+        const T dv0 = (p0 - lab0) / O, dv1 = (p1 - lab1) / O;   // gcn_mbgd_fp64.cu:352
+        if (has_s) {
+            d2s[s * 16 + o0] = dv0;
+            if (has1) d2s[s * 16 + o1] = dv1;
+        }
+        if (live) {
+            tr.d2[(long)(r0_done + s) * O + o0] = dv0;
+            if (has1) tr.d2[(long)(r0_done + s) * O + o1] = dv1;
+        }
+        __syncthreads();
+        if (live) {
+            for (int n = j8; n < H; n += 8) {
+                // bp_fully_connect(out -> hidden), gcn_mbgd_fp64.cu:416-434: 13-wide tree
+                T prod[O];
+#pragma unroll
+                for (int o = 0; o < O; o++) prod[o] = w2s[o + n * O] * d2s[s * 16 + o];
+                const T a = zr[n];
+                tr.a1[(long)(r0_done + s) * H + n] = a;
+                tr.d1[(long)(r0_done + s) * H + n] = tree13(prod) * (1 + a) * (1 - a);
+            }
+            if (j8 == 7) {   // one lane per sample: the 13 loss terms and their ordered sum
+                T ta[O], tb[O];
+                int lab[O];
+                for (int o = 0; o < O; o++) {
+                    lab[o] = tr.onehot[(long)(r0_done + s) * O + o];
+                    loss_terms(ps[s * 16 + o], lab[o], &ta[o], &tb[o]);
+                }
+                tr.loss_values[r0_done + s] = loss_sum(ta, tb, lab);
+            }
+        }
     }
     FC_STAMP(3);
     if (tile_next < 0) break;
@@ -567,33 +637,45 @@ struct FwdWs {
 
 // idx9 == null: `cubes` holds n pre-gathered cubes.  idx9 != null: `cubes` is the scene
 // [z][plane] and sample i is the pixel neighbourhood idx9[i][0..9).
+// Training (tr != null): samples [first, first + n) of `cubes` in ONE pass (the caller's pool
+// buffer holds all n rows), winners to px, the per-sample training outputs through tr.
 template <typename T, bool FLIP>
 int forward_impl(const T *params, const T *cubes, long n, int z, T *probs, int *argmax, void *ws,
-                 size_t ws_bytes, hipStream_t st, const int *idx9 = nullptr, long plane = 0)
+                 size_t ws_bytes, hipStream_t st, const int *idx9 = nullptr, long plane = 0,
+                 const FcTrainOut<T> *tr = nullptr, long first = 0, T *pool_out = nullptr, unsigned char *px = nullptr,
+                 int *ctr_out = nullptr)
 {
     ccnn_dims_t d;
     if (make_dims(z, &d)) return CCNN_E_INVALID;
-    if (!params || !cubes || n < 0 || (n > 0 && !ws)) return CCNN_E_INVALID;
+    if (!params || !cubes || n < 0 || (n > 0 && !ws && !tr)) return CCNN_E_INVALID;
     if (n == 0) return 0;
-    const long chunk = fwd_chunk_rows(d, sizeof(T));
+    const long chunk = tr ? n : fwd_chunk_rows(d, sizeof(T));
     const long rows = n < chunk ? n : chunk;
-    if (ws_bytes < FwdWs<T>::bytes(rows, d)) return CCNN_E_WORKSPACE;
-    FwdWs<T> w(ws, rows, d);
+    if (!tr && ws_bytes < FwdWs<T>::bytes(rows, d)) return CCNN_E_WORKSPACE;
+    FwdWs<T> w(tr ? nullptr : ws, rows, d);
+    if (tr) {
+        w.pool = pool_out;
+        w.ctr = ctr_out;
+    }
     const int nreg16 = ((d.cube + 63) / 64 + 15) / 16;   // prefetch registers per lane, in sixteens
     if (nreg16 > CONV_MAXREG / 16) return CCNN_E_RANGE;
-    typedef void (*ConvKern)(const T *, const T *, long, long, int, int, int, int, T *, const int *, long, int *);
-    static const ConvKern kern[2][4] = {
-        {conv_pool_fwd<T, FLIP, 16, false>, conv_pool_fwd<T, FLIP, 32, false>, conv_pool_fwd<T, FLIP, 48, false>,
-         conv_pool_fwd<T, FLIP, 64, false>},
-        {conv_pool_fwd<T, FLIP, 16, true>, conv_pool_fwd<T, FLIP, 32, true>, conv_pool_fwd<T, FLIP, 48, true>,
-         conv_pool_fwd<T, FLIP, 64, true>}};
-    const ConvKern conv = kern[idx9 != nullptr][nreg16 - 1];
+    typedef void (*ConvKern)(const T *, const T *, long, long, int, int, int, int, T *, const int *, long, int *,
+                             unsigned char *);
+    static const ConvKern kern[3][4] = {
+        {conv_pool_fwd<T, FLIP, 16, false, false>, conv_pool_fwd<T, FLIP, 32, false, false>,
+         conv_pool_fwd<T, FLIP, 48, false, false>, conv_pool_fwd<T, FLIP, 64, false, false>},
+        {conv_pool_fwd<T, FLIP, 16, true, false>, conv_pool_fwd<T, FLIP, 32, true, false>,
+         conv_pool_fwd<T, FLIP, 48, true, false>, conv_pool_fwd<T, FLIP, 64, true, false>},
+        {conv_pool_fwd<T, FLIP, 16, false, true>, conv_pool_fwd<T, FLIP, 32, false, true>,
+         conv_pool_fwd<T, FLIP, 48, false, true>, conv_pool_fwd<T, FLIP, 64, false, true>}};
+    const bool train = tr != nullptr;
+    const ConvKern conv = kern[train ? 2 : idx9 != nullptr][nreg16 - 1];
     // Waves per workgroup: the count (8, 4, 2 or 1) that puts the most waves on the device; LDS
     // (the filter image plus a cube and a pooled row per wave) and registers both limit it.
     int nwv = 0, resident = 0;
     size_t csm = 0;
     for (int w = CONV_MAXWAVES; w >= 1; w >>= 1) {
-        const size_t b = conv_smem<T>(d, w);
+        const size_t b = conv_smem<T>(d, w, train);
         if (b > 160 * 1024) continue;
         if (int e = allow_smem(conv, b)) return e;
         const int r = resident_blocks(reinterpret_cast<const void *>(conv), 64 * w, b);
@@ -604,10 +686,13 @@ int forward_impl(const T *params, const T *cubes, long n, int z, T *probs, int *
         }
     }
     if (nwv == 0) return CCNN_E_RANGE;
-    if (int e = allow_smem(fc_head_fwd<T, 32>, FcHeadLds<T, 32>::bytes)) return e;
-    if (int e = allow_smem(fc_head_fwd<T, 16>, FcHeadLds<T, 16>::bytes)) return e;
-    const int fc_res32 = resident_blocks(reinterpret_cast<const void *>(fc_head_fwd<T, 32>), 256, FcHeadLds<T, 32>::bytes);
-    const int fc_res16 = resident_blocks(reinterpret_cast<const void *>(fc_head_fwd<T, 16>), 256, FcHeadLds<T, 16>::bytes);
+    typedef void (*FcKern)(const T *, int, int, int, int, const T *, int, int, T *, int *, int *, FcTrainOut<T>);
+    const FcKern fc32 = train ? fc_head_fwd<T, 32, true> : fc_head_fwd<T, 32, false>;
+    const FcKern fc16 = train ? fc_head_fwd<T, 16, true> : fc_head_fwd<T, 16, false>;
+    if (int e = allow_smem(fc32, FcHeadLds<T, 32>::bytes)) return e;
+    if (int e = allow_smem(fc16, FcHeadLds<T, 16>::bytes)) return e;
+    const int fc_res32 = resident_blocks(reinterpret_cast<const void *>(fc32), 256, FcHeadLds<T, 32>::bytes);
+    const int fc_res16 = resident_blocks(reinterpret_cast<const void *>(fc16), 256, FcHeadLds<T, 16>::bytes);
     if (fc_res32 <= 0 || fc_res16 <= 0) return CCNN_E_RANGE;
     for (long s0 = 0; s0 < n; s0 += rows) {
         const int nr = (int)((n - s0) < rows ? (n - s0) : rows);
@@ -624,20 +709,36 @@ int forward_impl(const T *params, const T *cubes, long n, int z, T *probs, int *
             if (e != hipSuccess) return (int)e;
         }
         {
-            launch("conv_pool_fwd", conv, dim3(pg), dim3(64 * nwv), csm, st, params, cubes, s0, (long)nr, d.cube, d.re,
-                   d.mre, d.off_b0, w.pool, idx9, plane, w.ctr);
+            launch(train ? "conv_pool_fwd_train" : "conv_pool_fwd", conv, dim3(pg), dim3(64 * nwv), csm, st, params, cubes,
+                   first + s0, (long)nr, d.cube, d.re, d.mre, d.off_b0, w.pool, idx9, plane, w.ctr, px);
         }
         CCNN_LAUNCH_CHECK();
         {
-            launch("fc_head_fwd", small ? fc_head_fwd<T, 16> : fc_head_fwd<T, 32>, dim3(fg), dim3(256),
+            launch(train ? "fc_head_fwd_train" : "fc_head_fwd", small ? fc16 : fc32, dim3(fg), dim3(256),
                    small ? FcHeadLds<T, 16>::bytes : FcHeadLds<T, 32>::bytes, st,
                    params, d.off_w1, d.off_b1, d.off_w2, d.off_b2, w.pool, nr, d.pout,
-                   probs ? probs + s0 * O : nullptr, argmax ? argmax + s0 : nullptr, w.ctr);
+                   probs ? probs + s0 * O : nullptr, argmax ? argmax + s0 : nullptr, w.ctr,
+                   tr ? *tr : FcTrainOut<T>{});
         }
         CCNN_LAUNCH_CHECK();
     }
     return 0;
 }
+
+// The forward half of the batched minibatch step (train_fwd.h): conv + pool (+ winners) and
+// FC1 + head + deltas over samples [first, first + B) of `cubes`.
+template <typename T, bool FLIP>
+int train_forward(const T *params, const T *cubes, const int *onehot, long first, int B, int z, T *pool,
+                  unsigned char *px, T *a1, T *d1, T *d2, T *probs, double *loss_values, int *ctr, hipStream_t st)
+{
+    FcTrainOut<T> tr{onehot + first * O, a1, d1, d2, loss_values};
+    return forward_impl<T, FLIP>(params, cubes, B, z, probs, nullptr, nullptr, 0, st, nullptr, 0, &tr, first, pool, px, ctr);
+}
+template int train_forward<float, true>(const float *, const float *, const int *, long, int, int, float *,
+                                        unsigned char *, float *, float *, float *, float *, double *, int *, hipStream_t);
+template int train_forward<double, false>(const double *, const double *, const int *, long, int, int, double *,
+                                          unsigned char *, double *, double *, double *, double *, double *, int *,
+                                          hipStream_t);
 
 }  // namespace ccnn
 

@@ -19,9 +19,13 @@
 // matrix-vector product per sample here, read through L2.
 #include <mutex>
 
+#include <cstdlib>
+#include <cstring>
+
 #include "ccnn_device.h"
 #include "comm.h"
 #include "profile.h"
+#include "train_fwd.h"
 
 // Diagnostic builds only (-DCCNN_FB_TIMING): workgroup 5 of sample_fwd_bwd stamps the wall clock
 // (100 MHz) at FB_TICK(k); ccnn_debug_fb_ticks() returns the stamps of the last launch.
@@ -475,7 +479,7 @@ __device__ __forceinline__ T colsum8(int B, int rg, int c, T *red, Term term)
 #pragma unroll
         for (int u = 0; u < 16; u++) {
             const int b = b0 + 8 * u;
-            const T x = term(b < B ? b : B - 1);   // clamped load, masked value
+            const T x = term(b < B ? b : (B > 0 ? B - 1 : 0));   // clamped load, masked value (B == 0: row 0 exists, unused)
             v[u] = b < B ? x : T(0);
         }
 #pragma unroll
@@ -497,6 +501,11 @@ __device__ __forceinline__ T colsum8(int B, int rg, int c, T *red, Term term)
 // raises its flag there, waits for the same workgroup of every rank and adds the world
 // contributions in rank order before `upd` sees them (comm.h).  No grid-wide barrier: a
 // workgroup only depends on its namesakes on the other ranks.
+//
+// gridDim.y > 1 (large batches): split y sums only rows [y Bs, (y+1) Bs) of the batch (and of the
+// conv-gradient slab, whose row count need not be B) and stores its sums in grad + y * grad_stride;
+// apply_partials then adds the splits in order.  A single 2048-row sum per thread would be 16
+// dependent rounds of loads.
 template <typename T, int KF>
 __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int off_w1, int off_b1,
                                                           int off_w2, int off_b2,
@@ -504,13 +513,27 @@ __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int o
                                                           const T *__restrict__ a1,
                                                           const T *__restrict__ d1,
                                                           const T *__restrict__ d2,
-                                                          const T *__restrict__ slab, int nb_w1,
+                                                          const T *__restrict__ slab, int slab_rows, int nb_w1,
                                                           int nb_w0, int nb_w2, T *__restrict__ grad,
-                                                          UpdateRule<T> upd, CommDev xc, unsigned xstep)
+                                                          long grad_stride, UpdateRule<T> upd, CommDev xc,
+                                                          unsigned xstep)
 {
     __shared__ T red[8 * 64];
     const int tid = threadIdx.x;
     int blk = blockIdx.x;
+    if (gridDim.y > 1) {
+        const int y = blockIdx.y, ny = gridDim.y;
+        const int bs = (B + ny - 1) / ny, b_lo = min(y * bs, B);
+        pool += (long)b_lo * pout;
+        a1 += (long)b_lo * H;
+        d1 += (long)b_lo * H;
+        d2 += (long)b_lo * O;
+        B = min(bs, B - b_lo);
+        const int ss = (slab_rows + ny - 1) / ny, s_lo = min(y * ss, slab_rows);
+        slab_rows = min(ss, slab_rows - s_lo);
+        if (slab_rows > 0) slab += (long)s_lo * (F * K + F);   // an empty share keeps pointing at row 0 (loads are clamped, unmasked values unused)
+        grad += y * grad_stride;
+    }
     int ok[4] = {-1, -1, -1, -1};   // parameter index of this thread's outputs (-1: none)
     T og[4] = {0, 0, 0, 0};         // and their batch sums
     if (blk < nb_w1) {
@@ -554,7 +577,7 @@ __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int o
         const int c = tid & 63, rg = tid >> 6;
         if (blk < nb_w0) {
             const int k = min(blk * 64 + c, F * K + F - 1);
-            const T tot = colsum8<T>(B, rg, c, red, [&](int b) { return slab[(long)b * (F * K + F) + k]; });
+            const T tot = colsum8<T>(slab_rows, rg, c, red, [&](int b) { return slab[(long)b * (F * K + F) + k]; });
             if (rg == 0 && blk * 64 + c < F * K + F) {   // slab layout = W0 | b0 = params[0..)
                 ok[0] = k;
                 og[0] = tot;
@@ -651,17 +674,434 @@ __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int o
         if (ok[j] >= 0) upd.apply(grad, ok[j], og[j]);
 }
 
+
+// ===========================================================================
+// Batched path (large minibatches).  The per-sample kernel above re-reads all of W1 twice per
+// sample; here every layer runs over the whole batch:
+//   conv_pool_fwd<TRAIN> + fc_head_fwd<TRAIN>   forward, loss, delta2, delta1        (forward.hip)
+//   dpool_bwd        dpool = (delta1 W1^T)(1 + pool)(1 - pool): one [B x 100] x [100 x Pout] product
+//   conv_bwd_batch   bp_maxpooling scatter + conv gradient, accumulated over a workgroup's samples
+//   grad_reduce      dW1 = pool^T delta1, dW2, db1, db2, and the column sums of conv_bwd_batch's partials
+//   apply_partials   adds grad_reduce's batch splits in order and applies the update
+// W1 is read once per 16-row tile of the products instead of twice per sample.
+
+// dpool[b][p] = (sum_n W1[n + 100 p] d1[b][n]) (1 + pool[b][p]) (1 - pool[b][p])
+// (bp_fully_connect hidden -> pool, gcn_mbgd_fp64.cu:416-434, batched).  Rows of the MFMA tile =
+// 16 pooled features (A = 16 rows of W1, held in registers for the whole workgroup), columns =
+// 16 samples (B = 16 rows of d1).  Both operands are contiguous along n, so each lane fetches
+// 16-byte vectors and the product's k order is permuted to match: k-step s of lane group kq
+// takes n = VW kq + (s mod VW) + 4 VW (s / VW) - the same permutation on both sides.
+constexpr int DP_THREADS = 256;
+template <typename T>
+__global__ __launch_bounds__(DP_THREADS) void dpool_bwd(const T *__restrict__ W1, const T *__restrict__ d1,
+                                                        const T *__restrict__ pool, T *__restrict__ dp, int B,
+                                                        int pout, int tiles_per_wave)
+{
+    typedef typename Vec16<T>::type V;
+    constexpr int VW = Vec16<T>::W;
+    constexpr int NG = (H + 4 * VW - 1) / (4 * VW);   // vectors per lane along n
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const int p0 = blockIdx.x * 16;
+    const int prow = min(p0 + col, pout - 1);          // clamped: loads stay in bounds, stores masked
+    V a[NG];
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        const int n = VW * kq + 4 * VW * g;
+        a[g] = reinterpret_cast<const V *>(W1 + (long)prow * H)[min(n, H - VW) / VW];
+        if (n >= H) a[g] = V{};
+    }
+    const int btiles = (B + 15) >> 4;
+    const int bt0 = (blockIdx.y * (DP_THREADS / 64) + wave) * tiles_per_wave;
+    for (int bt = bt0; bt < min(bt0 + tiles_per_wave, btiles); bt++) {
+        const int b0 = bt * 16;
+        const int brow = min(b0 + col, B - 1);
+        V w[NG];
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            const int n = VW * kq + 4 * VW * g;
+            w[g] = reinterpret_cast<const V *>(d1 + (long)brow * H)[min(n, H - VW) / VW];   // lanes past n = 100 meet a zero in a[]
+        }
+        typename Mma<T>::acc_t acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int g = 0; g < NG; g++)
+#pragma unroll
+            for (int j = 0; j < VW; j++) acc = Mma<T>::mma(a[g][j], w[g][j], acc);
+        // lane holds sample b0 + col, features p0 + Mma::row(lane, 0..3)
+        const int b = b0 + col;
+        if (b < B) {
+            if (sizeof(T) == 4) {
+                // f32 result map: rows 4 q .. 4 q + 3 are consecutive features: one 16-byte access
+                // each way (pout is a multiple of 4, so a vector is wholly inside or outside)
+                const int p = p0 + 4 * kq;
+                if (p < pout) {
+                    const V pv = *reinterpret_cast<const V *>(pool + (long)b * pout + p);
+                    V o;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[r % VW] = acc[r] * (1 + pv[r % VW]) * (1 - pv[r % VW]);
+                    *reinterpret_cast<V *>(dp + (long)b * pout + p) = o;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int p = p0 + Mma<T>::row(lane, r);
+                    if (p < pout) {
+                        const T pv = pool[(long)b * pout + p];
+                        dp[(long)b * pout + p] = acc[r] * (1 + pv) * (1 - pv);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// bp_maxpooling + bp_convolution over a workgroup's share of the batch
+// (gcn_mbgd_fp64.cu:439-496): per sample the delta of each pooled feature goes to the position
+// that won its pair, and dW0[f][tap] += sum_t delta[f][t] cube[18 t + tap] is the [20 x re] x
+// [re x 171] MFMA product of conv_bwd_tiles - but the accumulators live across the workgroup's
+// samples, so what reaches memory is one [F K + F] partial per WORKGROUP, not per sample.
+// 11 waves, one per 16-tap tile (both filter tiles each): no wave shares an output with another,
+// so nothing is reduced across waves.  Cube and delta image are double-buffered in LDS (NBUF = 2,
+// or 1 where two do not fit): the next sample is staged while the current one is multiplied.
+// part[g][f K + tap] = sum / re, part[g][F K + f] = sum_m dp (1 + pool)(1 - pool) / re (the
+// reference's second tanh' on the bias path, :487-488; at a winner the conv output is the pooled value).
+constexpr int CB_WAVES = 11;
+constexpr int CB_THREADS = 64 * CB_WAVES;
+template <typename T>
+struct ConvBwdLds {
+    int cube_len, delta_len, dps_len, per_buf;
+    __host__ __device__ ConvBwdLds(int re, int mre)
+    {
+        cube_len = up4(conv_cube_pad(re));
+        delta_len = 2 * 4 * ((re + 3) >> 2) * LDWK;
+        dps_len = up4(F * mre);
+        per_buf = cube_len + delta_len + dps_len;
+    }
+    size_t bytes(int nbuf) const { return (size_t)nbuf * per_buf * sizeof(T); }
+};
+
+template <typename T, int NBUF>
+__global__ __launch_bounds__(CB_THREADS) void conv_bwd_batch(const T *__restrict__ cubes, long first,
+                                                             const T *__restrict__ dp, const T *__restrict__ pool,
+                                                             const unsigned char *__restrict__ px, int B,
+                                                             int cube_elems, int re, int mre, T *__restrict__ part)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ConvBwdLds<T> L(re, mre);
+    T *base = reinterpret_cast<T *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const int pout = F * mre, ks = (re + 3) >> 2, ldd = 4 * ks * LDWK;
+    const int G = gridDim.x;
+    auto buf_cube = [&](int i) { return base + (NBUF == 2 ? i : 0) * L.per_buf; };
+    auto buf_delta = [&](int i) { return buf_cube(i) + L.cube_len; };
+    auto buf_dps = [&](int i) { return buf_delta(i) + L.delta_len; };
+
+    // stage sample b into buffer i: cube (zero-padded), zeroed delta image, then the scatter
+    constexpr int NCR = (NB * CCNN_MAX_BANDS + CB_THREADS - 1) / CB_THREADS;                      // cube elements per thread
+    constexpr int NPU = (F * ((((CCNN_MAX_BANDS - 20) / 2 + 1) + 1) / 2) + CB_THREADS - 1) / CB_THREADS;   // pooled features per thread
+    auto stage_loads = [&](int b, T(&cr)[NCR], T(&dv)[NPU], T(&pv)[NPU], unsigned(&bit)[NPU]) {
+        const T *src = cubes + (first + b) * (long)cube_elems;
+#pragma unroll
+        for (int u = 0; u < NCR; u++) cr[u] = src[min(u * CB_THREADS + tid, cube_elems - 1)];
+#pragma unroll
+        for (int u = 0; u < NPU; u++) {
+            const int p = min(u * CB_THREADS + tid, pout - 1);
+            dv[u] = dp[(long)b * pout + p];
+            pv[u] = pool[(long)b * pout + p];
+            bit[u] = px[(long)b * pout + p];
+        }
+    };
+    auto stage_zero = [&](int i) {
+        T *cube = buf_cube(i), *dl = buf_delta(i);
+        for (int e = cube_elems + tid; e < L.cube_len; e += CB_THREADS) cube[e] = 0;
+        for (int e = tid; e < L.delta_len; e += CB_THREADS) dl[e] = 0;
+    };
+    auto stage_cube = [&](int i, const T(&cr)[NCR]) {
+        T *cube = buf_cube(i);
+#pragma unroll
+        for (int u = 0; u < NCR; u++) {
+            const int e = u * CB_THREADS + tid;
+            if (e < cube_elems) cube[e] = cr[u];
+        }
+    };
+    auto stage_scatter = [&](int i, const T(&dv)[NPU], const T(&pv)[NPU], const unsigned(&bit)[NPU]) {
+        T *dl = buf_delta(i), *dps = buf_dps(i);
+#pragma unroll
+        for (int u = 0; u < NPU; u++) {
+            const int p = u * CB_THREADS + tid;
+            if (p < pout) {
+                const int f = p / mre, m = p - f * mre;
+                dl[(f >> 4) * ldd + (2 * m + (int)bit[u]) * LDWK + (f & 15)] = dv[u];
+                dps[p] = dv[u] * (1 + pv[u]) * (1 - pv[u]);
+            }
+        }
+    };
+
+    typename Mma<T>::acc_t c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+    T bsum = 0;   // lanes 0..19 of wave 0: the bias path of filter `lane`
+    int b = blockIdx.x;
+    if (b >= B) {   // no sample for this workgroup: its partial is zero
+        for (int e = tid; e < F * K + F; e += CB_THREADS) part[(long)blockIdx.x * (F * K + F) + e] = 0;
+        return;
+    }
+    // Two samples ahead: set A holds the sample that is staged into LDS next, set B receives the
+    // loads of the one after it, so a load has a whole multiply phase plus a staging phase to land.
+    struct Regs {
+        T cr[NCR], dv[NPU], pv[NPU];
+        unsigned bit[NPU];
+    } ra, rb;
+    stage_loads(b, ra.cr, ra.dv, ra.pv, ra.bit);
+    stage_zero(0);
+    stage_cube(0, ra.cr);
+    __syncthreads();   // delta image zeroed before anybody scatters into it
+    stage_scatter(0, ra.dv, ra.pv, ra.bit);
+    if (b + G < B) stage_loads(b + G, ra.cr, ra.dv, ra.pv, ra.bit);
+    __syncthreads();
+    int cur = 0;
+    // one sample: multiply buffer `cur`, stage the sample held in `nx` (if any) for the next
+    // round, load the sample after that into `ld`
+    auto round = [&](int bb, Regs &nx, Regs &ld) {
+        const bool more = bb + G < B;
+        if (bb + 2 * G < B) stage_loads(bb + 2 * G, ld.cr, ld.dv, ld.pv, ld.bit);
+        if (NBUF == 2 && more) stage_zero(cur ^ 1);
+        {
+            const T *cube = buf_cube(cur), *dl = buf_delta(cur);
+            const T *ap0 = dl + kq * LDWK + col, *ap1 = ap0 + ldd;
+            const T *bp = cube + WSTEP * kq + wave * 16 + col;
+            int s = 0;
+            for (; s + 2 <= ks; s += 2) {
+                const T a00 = ap0[4 * s * LDWK], a10 = ap1[4 * s * LDWK], b0 = bp[4 * s * WSTEP];
+                const T a01 = ap0[4 * (s + 1) * LDWK], a11 = ap1[4 * (s + 1) * LDWK], b1 = bp[4 * (s + 1) * WSTEP];
+                c0 = Mma<T>::mma(a00, b0, c0);
+                c1 = Mma<T>::mma(a10, b0, c1);
+                c0 = Mma<T>::mma(a01, b1, c0);
+                c1 = Mma<T>::mma(a11, b1, c1);
+            }
+            if (s < ks) {
+                const T a00 = ap0[4 * s * LDWK], a10 = ap1[4 * s * LDWK], b0 = bp[4 * s * WSTEP];
+                c0 = Mma<T>::mma(a00, b0, c0);
+                c1 = Mma<T>::mma(a10, b0, c1);
+            }
+            if (wave == 0 && lane < F) {
+                const T *dps = buf_dps(cur);
+                T mid1 = 0;
+                for (int m = 0; m < mre; m++) mid1 = mid1 + dps[lane * mre + m];
+                bsum = bsum + mid1;
+            }
+        }
+        if (NBUF == 2) {
+            if (more) stage_cube(cur ^ 1, nx.cr);
+            __syncthreads();   // next image zeroed and its cube in place; current buffers no longer read
+            if (more) stage_scatter(cur ^ 1, nx.dv, nx.pv, nx.bit);
+            __syncthreads();
+            cur ^= 1;
+        } else {
+            __syncthreads();   // everyone is done reading the only buffer
+            if (more) {
+                stage_zero(0);
+                stage_cube(0, nx.cr);
+            }
+            __syncthreads();
+            if (more) stage_scatter(0, nx.dv, nx.pv, nx.bit);
+            __syncthreads();
+        }
+    };
+    for (; b < B; b += 2 * G) {
+        round(b, ra, rb);
+        if (b + G < B) round(b + G, rb, ra);
+    }
+    T *out = part + (long)blockIdx.x * (F * K + F);
+    const int tap = wave * 16 + col;
+    if (tap < K) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int f0 = Mma<T>::row(lane, r), f1 = 16 + f0;
+            out[f0 * K + tap] = c0[r] / re;   // gcn_mbgd_fp64.cu:491
+            if (f1 < F) out[f1 * K + tap] = c1[r] / re;
+        }
+    }
+    if (wave == 0 && lane < F) out[F * K + lane] = bsum / re;
+}
+
+// The same product with the staging taken off the multiplying waves: a 12th wave alone moves the
+// next sample into the other LDS buffer (cube, zeroed delta image, scatter, bias-path sums) while
+// the 11 tile waves multiply the current one; one workgroup barrier per sample.  Used when two
+// buffers fit in LDS; conv_bwd_batch<T, 1> above is the fallback.
+constexpr int CS_THREADS = 64 * (CB_WAVES + 1);
+template <typename T>
+__global__ __launch_bounds__(CS_THREADS) void conv_bwd_staged(const T *__restrict__ cubes, long first,
+                                                              const T *__restrict__ dp, const T *__restrict__ pool,
+                                                              const unsigned char *__restrict__ px, int B,
+                                                              int cube_elems, int re, int mre, T *__restrict__ part)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ConvBwdLds<T> L(re, mre);
+    T *base = reinterpret_cast<T *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const int pout = F * mre, ks = (re + 3) >> 2, ldd = 4 * ks * LDWK;
+    const int G = gridDim.x;
+    T *out = part + (long)blockIdx.x * (F * K + F);
+    if ((int)blockIdx.x >= B) {   // no sample for this workgroup: its partial is zero
+        for (int e = tid; e < F * K + F; e += CS_THREADS) out[e] = 0;
+        return;
+    }
+    const int nsamp = (B - (int)blockIdx.x + G - 1) / G;   // samples blockIdx.x, + G, ..
+    if (wave == CB_WAVES) {
+        // ---- the staging wave
+        constexpr int NCR = (NB * CCNN_MAX_BANDS + 63) / 64;
+        constexpr int NPU = (F * ((((CCNN_MAX_BANDS - 20) / 2 + 1) + 1) / 2) + 63) / 64;
+        const int ncr = (cube_elems + 63) >> 6, npu = (pout + 63) >> 6;   // wave-uniform trip counts
+        T bsum = 0;   // lanes 0..19: bias path of filter `lane`, summed over the samples
+        for (int i = 0; i < nsamp; i++) {
+            const int b = blockIdx.x + i * G;
+            T *cube = base + (i & 1) * L.per_buf, *dl = cube + L.cube_len, *dps = dl + L.delta_len;
+            // loads first (clamped, unconditional, 16 in flight), zeroing while they fly
+            const T *src = cubes + (first + b) * (long)cube_elems;
+            typedef typename Vec16<T>::type V;
+            constexpr int VW = Vec16<T>::W;
+            for (int e = lane; e < L.delta_len / VW; e += 64) reinterpret_cast<V *>(dl)[e] = V{};
+            for (int e = cube_elems + lane; e < L.cube_len; e += 64) cube[e] = 0;
+#pragma unroll 1
+            for (int u0 = 0; u0 < ncr; u0 += 16) {
+                T t[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) t[u] = src[min((u0 + u) * 64 + lane, cube_elems - 1)];
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const int e = (u0 + u) * 64 + lane;
+                    if (e < cube_elems) cube[e] = t[u];
+                }
+            }
+            wave_sync();   // the image is zero before this wave scatters into it
+#pragma unroll 1
+            for (int u0 = 0; u0 < npu; u0 += 8) {
+                T dv[8], pv[8];
+                unsigned bit[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int p = min((u0 + u) * 64 + lane, pout - 1);
+                    dv[u] = dp[(long)b * pout + p];
+                    pv[u] = pool[(long)b * pout + p];
+                    bit[u] = px[(long)b * pout + p];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int p = (u0 + u) * 64 + lane;
+                    if (p < pout) {
+                        const int f = p / mre, m = p - f * mre;
+                        dl[(f >> 4) * ldd + (2 * m + (int)bit[u]) * LDWK + (f & 15)] = dv[u];
+                        dps[p] = dv[u] * (1 + pv[u]) * (1 - pv[u]);
+                    }
+                }
+            }
+            wave_sync();
+            if (lane < F) {
+                T mid1 = 0;
+                for (int m = 0; m < mre; m++) mid1 = mid1 + dps[lane * mre + m];
+                bsum = bsum + mid1;
+            }
+            (void)NCR;
+            (void)NPU;
+            __syncthreads();   // sample i is staged (and the tile waves are done with sample i - 1)
+        }
+        __syncthreads();       // pairs with the tile waves' last barrier
+        if (lane < F) out[F * K + lane] = bsum / re;
+        return;
+    }
+    // ---- the 11 tile waves
+    typename Mma<T>::acc_t c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+    __syncthreads();   // sample 0 staged
+    for (int i = 0; i < nsamp; i++) {
+        const T *cube = base + (i & 1) * L.per_buf, *dl = cube + L.cube_len;
+        const T *ap0 = dl + kq * LDWK + col, *ap1 = ap0 + ldd;
+        const T *bp = cube + WSTEP * kq + wave * 16 + col;
+        int s = 0;
+        for (; s + 2 <= ks; s += 2) {
+            const T a00 = ap0[4 * s * LDWK], a10 = ap1[4 * s * LDWK], b0 = bp[4 * s * WSTEP];
+            const T a01 = ap0[4 * (s + 1) * LDWK], a11 = ap1[4 * (s + 1) * LDWK], b1 = bp[4 * (s + 1) * WSTEP];
+            c0 = Mma<T>::mma(a00, b0, c0);
+            c1 = Mma<T>::mma(a10, b0, c1);
+            c0 = Mma<T>::mma(a01, b1, c0);
+            c1 = Mma<T>::mma(a11, b1, c1);
+        }
+        if (s < ks) {
+            const T a00 = ap0[4 * s * LDWK], a10 = ap1[4 * s * LDWK], b0 = bp[4 * s * WSTEP];
+            c0 = Mma<T>::mma(a00, b0, c0);
+            c1 = Mma<T>::mma(a10, b0, c1);
+        }
+        __syncthreads();   // done with sample i; sample i + 1 is staged
+    }
+    const int tap = wave * 16 + col;
+    if (tap < K) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int f0 = Mma<T>::row(lane, r), f1 = 16 + f0;
+            out[f0 * K + tap] = c0[r] / re;   // gcn_mbgd_fp64.cu:491
+            if (f1 < F) out[f1 * K + tap] = c1[r] / re;
+        }
+    }
+}
+
+// w -= lr * (sum over the S batch splits, in order) [/ divisor], or grad = that sum.
+template <typename T>
+__global__ void apply_partials(const T *__restrict__ part, int S, long stride, int n, T *__restrict__ grad,
+                               UpdateRule<T> upd)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    T tot = 0;
+    for (int s = 0; s < S; s++) tot = tot + part[s * stride + k];
+    upd.apply(grad, k, tot);
+}
+
 // ---------------------------------------------------------------------------
+// Which path a batch of B takes: the fused per-sample kernel is the faster one while a batch
+// fills the chip with at most one workgroup per CU; CCNN_MBGD_PATH=fused|batched overrides (tests
+// run both on the same inputs).
+constexpr int BATCHED_MIN_B = 256;
+constexpr int BATCHED_MAX_PARTIALS = 256;   // workgroups (= partial gradient rows) of conv_bwd_batch
+constexpr int BATCHED_SPLIT_ROWS = 256;     // rows of the batch one grad_reduce split sums
+constexpr int BATCHED_MAX_SPLITS = 16;
+inline bool use_batched(int B)
+{
+    if (const char *e = getenv("CCNN_MBGD_PATH")) {
+        if (!strcmp(e, "batched")) return true;
+        if (!strcmp(e, "fused")) return false;
+    }
+    return B >= BATCHED_MIN_B;
+}
+inline int batched_splits(int B)
+{
+    const int s = (B + BATCHED_SPLIT_ROWS - 1) / BATCHED_SPLIT_ROWS;
+    return s < 1 ? 1 : s > BATCHED_MAX_SPLITS ? BATCHED_MAX_SPLITS : s;
+}
+
 template <typename T>
 struct MbgdWs {
     T *pool, *a1, *d1, *d2, *slab, *probs;
+    // batched path only
+    T *dp, *parts, *gsum;
+    unsigned char *px;
+    int *ctr;
     static size_t bytes(int B, const ccnn_dims_t &d)
     {
         size_t b = 0;
         b += align_up((size_t)B * d.pout * sizeof(T));          // pool
         b += 2 * align_up((size_t)B * H * sizeof(T));           // a1, d1
         b += 2 * align_up((size_t)B * O * sizeof(T));           // d2, probs
-        b += align_up((size_t)B * (F * K + F) * sizeof(T));     // per-sample conv gradient tiles
+        if (!use_batched(B)) {
+            b += align_up((size_t)B * (F * K + F) * sizeof(T));     // per-sample conv gradient tiles
+        } else {
+            const int G = B < BATCHED_MAX_PARTIALS ? B : BATCHED_MAX_PARTIALS;
+            b += align_up((size_t)G * (F * K + F) * sizeof(T));     // per-workgroup conv gradient partials
+            b += align_up((size_t)B * d.pout * sizeof(T));          // dpool
+            b += align_up((size_t)B * d.pout);                      // pool winners, one byte each
+            b += align_up((size_t)batched_splits(B) * d.nparams * sizeof(T));   // grad_reduce's batch splits
+            b += align_up((size_t)d.nparams * sizeof(T));           // summed gradient (multi-GPU exchange)
+            b += align_up(TRAIN_CTR_INTS * sizeof(int));
+        }
         return b;
     }
     MbgdWs(void *ws, int B, const ccnn_dims_t &d)
@@ -672,29 +1112,43 @@ struct MbgdWs {
         d1 = c.take<T>((size_t)B * H);
         d2 = c.take<T>((size_t)B * O);
         probs = c.take<T>((size_t)B * O);
-        slab = c.take<T>((size_t)B * (F * K + F));
+        dp = parts = gsum = nullptr;
+        px = nullptr;
+        ctr = nullptr;
+        if (!use_batched(B)) {
+            slab = c.take<T>((size_t)B * (F * K + F));
+        } else {
+            const int G = B < BATCHED_MAX_PARTIALS ? B : BATCHED_MAX_PARTIALS;
+            slab = c.take<T>((size_t)G * (F * K + F));
+            dp = c.take<T>((size_t)B * d.pout);
+            px = c.take<unsigned char>((size_t)B * d.pout);
+            parts = c.take<T>((size_t)batched_splits(B) * d.nparams);
+            gsum = c.take<T>((size_t)d.nparams);
+            ctr = c.take<int>(TRAIN_CTR_INTS);
+        }
     }
 };
 
-// grad != null: store the batch-summed gradient.  grad == null: apply `upd` in place.
-template <typename T, bool FLIP>
-int mbgd_impl(const T *params, const T *cubes, const int *onehot, long first, int B, int z, T *grad,
-              UpdateRule<T> upd, double *loss_values, T *probs, void *ws, size_t ws_bytes,
-              hipStream_t st, ccnn_comm *cm = nullptr)
+template <typename T>
+int exchange_update(ccnn_comm *cm, T *params, const T *grad, const UpdateRule<T> &upd, int z, long n, hipStream_t st);
+template <>
+int exchange_update<float>(ccnn_comm *cm, float *params, const float *grad, const UpdateRule<float> &upd, int z, long,
+                           hipStream_t st)
 {
-    ccnn_dims_t d;
-    if (make_dims(z, &d)) return CCNN_E_INVALID;
-    if (!params || !cubes || !onehot || !loss_values || !ws || B <= 0 || first < 0) return CCNN_E_INVALID;
-    if (!grad && !upd.params) return CCNN_E_INVALID;
-    if (ws_bytes < MbgdWs<T>::bytes(B, d)) return CCNN_E_WORKSPACE;
-    MbgdWs<T> w(ws, B, d);
-    const FusedLayout L = fused_layout<T>(d.re, d.mre);
-    if (int e = allow_smem(sample_fwd_bwd<T, FLIP, FB_THREADS>, L.bytes)) return e;
-    {
-        launch("sample_fwd_bwd", sample_fwd_bwd<T, FLIP, FB_THREADS>, dim3(B), dim3(FB_THREADS), L.bytes, st, params, cubes, onehot, first,
-               d, w.pool, w.a1, w.d1, w.d2, probs, loss_values, w.slab);
-    }
-    CCNN_LAUNCH_CHECK();
+    return ccnn_allreduce_update_f32(cm, params, grad, upd.lr, z, upd.frozen_hi > upd.frozen_lo, st);
+}
+template <>
+int exchange_update<double>(ccnn_comm *cm, double *params, const double *grad, const UpdateRule<double> &upd, int,
+                            long n, hipStream_t st)
+{
+    return ccnn_allreduce_update_f64(cm, params, grad, upd.lr, upd.divisor, n, st);
+}
+
+// The two launches every path ends with share this: batch sums (+ update / exchange).
+template <typename T>
+int launch_grad_reduce(int B, const ccnn_dims_t &d, const MbgdWs<T> &w, int slab_rows, int splits, T *grad,
+                       long grad_stride, UpdateRule<T> upd, ccnn_comm *cm, hipStream_t st)
+{
     const int nb_w1 = (d.pout + 15) / 16;
     const int nb_w0 = (F * K + F + 63) / 64;
     const int nb_w2 = (H * O + 63) / 64;
@@ -711,14 +1165,79 @@ int mbgd_impl(const T *params, const T *cubes, const int *onehot, long first, in
         xc = cm->dev;
         xstep = cm->next_step();
     }
-    {
-        const bool narrow = sizeof(T) == 8 && cm && cm->shared_device;
-        launch("grad_reduce", narrow ? grad_reduce<T, 16> : grad_reduce<T, 32>, dim3(nblocks), dim3(GR_THREADS), 0, st, B,
-               d.pout, d.off_w1, d.off_b1, d.off_w2, d.off_b2, w.pool, w.a1, w.d1, w.d2, w.slab, nb_w1, nb_w0, nb_w2,
-               grad, upd, xc, xstep);
-    }
+    const bool narrow = sizeof(T) == 8 && cm && cm->shared_device;
+    launch("grad_reduce", narrow ? grad_reduce<T, 16> : grad_reduce<T, 32>, dim3(nblocks, splits), dim3(GR_THREADS), 0, st,
+           B, d.pout, d.off_w1, d.off_b1, d.off_w2, d.off_b2, w.pool, w.a1, w.d1, w.d2, w.slab, slab_rows, nb_w1, nb_w0,
+           nb_w2, grad, grad_stride, upd, xc, xstep);
     CCNN_LAUNCH_CHECK();
     return 0;
+}
+
+template <typename T, bool FLIP>
+int mbgd_batched(const T *params, const T *cubes, const int *onehot, long first, int B, int z, const ccnn_dims_t &d,
+                 T *grad, UpdateRule<T> upd, double *loss_values, T *probs, MbgdWs<T> &w, hipStream_t st, ccnn_comm *cm)
+{
+    if (int e = train_forward<T, FLIP>(params, cubes, onehot, first, B, z, w.pool, w.px, w.a1, w.d1, w.d2, probs,
+                                       loss_values, w.ctr, st))
+        return e;
+    {
+        const int btiles = (B + 15) / 16, waves = DP_THREADS / 64;
+        int gy = (btiles + waves - 1) / waves;
+        if (gy > 8) gy = 8;
+        const int tpw = (btiles + gy * waves - 1) / (gy * waves);
+        launch("dpool_bwd", dpool_bwd<T>, dim3((d.pout + 15) / 16, gy), dim3(DP_THREADS), 0, st, params + d.off_w1,
+               (const T *)w.d1, (const T *)w.pool, w.dp, B, d.pout, tpw);
+        CCNN_LAUNCH_CHECK();
+    }
+    const int G = B < BATCHED_MAX_PARTIALS ? B : BATCHED_MAX_PARTIALS;
+    {
+        const ConvBwdLds<T> L(d.re, d.mre);
+        const bool two = L.bytes(2) <= 150 * 1024;
+        auto kern = two ? conv_bwd_staged<T> : conv_bwd_batch<T, 1>;
+        const size_t smem = L.bytes(two ? 2 : 1);
+        if (int e = allow_smem(kern, smem)) return e;
+        launch("conv_bwd_batch", kern, dim3(G), dim3(two ? CS_THREADS : CB_THREADS), smem, st, cubes, first,
+               (const T *)w.dp, (const T *)w.pool, (const unsigned char *)w.px, B, d.cube, d.re, d.mre, w.slab);
+        CCNN_LAUNCH_CHECK();
+    }
+    const int S = batched_splits(B);
+    if (S == 1) return launch_grad_reduce<T>(B, d, w, G, 1, grad, 0, upd, cm, st);
+    // splits: partial sums first, then one pass that adds them in order and updates (or, across
+    // GPUs, stores the sum for the exchange + update kernel)
+    if (int e = launch_grad_reduce<T>(B, d, w, G, S, w.parts, d.nparams, UpdateRule<T>{}, nullptr, st)) return e;
+    T *out = cm ? w.gsum : grad;
+    UpdateRule<T> rule = cm ? UpdateRule<T>{} : upd;
+    launch("apply_partials", apply_partials<T>, dim3((d.nparams + 255) / 256), dim3(256), 0, st, (const T *)w.parts, S,
+           (long)d.nparams, d.nparams, out, rule);
+    CCNN_LAUNCH_CHECK();
+    if (cm) {
+        if (!upd.params) return CCNN_E_INVALID;
+        return exchange_update<T>(cm, upd.params, w.gsum, upd, z, d.nparams, st);
+    }
+    return 0;
+}
+
+// grad != null: store the batch-summed gradient.  grad == null: apply `upd` in place.
+template <typename T, bool FLIP>
+int mbgd_impl(const T *params, const T *cubes, const int *onehot, long first, int B, int z, T *grad,
+              UpdateRule<T> upd, double *loss_values, T *probs, void *ws, size_t ws_bytes,
+              hipStream_t st, ccnn_comm *cm = nullptr)
+{
+    ccnn_dims_t d;
+    if (make_dims(z, &d)) return CCNN_E_INVALID;
+    if (!params || !cubes || !onehot || !loss_values || !ws || B <= 0 || first < 0) return CCNN_E_INVALID;
+    if (!grad && !upd.params) return CCNN_E_INVALID;
+    if (ws_bytes < MbgdWs<T>::bytes(B, d)) return CCNN_E_WORKSPACE;
+    MbgdWs<T> w(ws, B, d);
+    if (use_batched(B)) return mbgd_batched<T, FLIP>(params, cubes, onehot, first, B, z, d, grad, upd, loss_values, probs, w, st, cm);
+    const FusedLayout L = fused_layout<T>(d.re, d.mre);
+    if (int e = allow_smem(sample_fwd_bwd<T, FLIP, FB_THREADS>, L.bytes)) return e;
+    {
+        launch("sample_fwd_bwd", sample_fwd_bwd<T, FLIP, FB_THREADS>, dim3(B), dim3(FB_THREADS), L.bytes, st, params, cubes, onehot, first,
+               d, w.pool, w.a1, w.d1, w.d2, probs, loss_values, w.slab);
+    }
+    CCNN_LAUNCH_CHECK();
+    return launch_grad_reduce<T>(B, d, w, B, 1, grad, 0, upd, cm, st);
 }
 
 }  // namespace ccnn

@@ -23,3 +23,11 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name))
     return load
+
+
+@pytest.fixture(params=["fused", "batched"])
+def mbgd_path(request, monkeypatch):
+    """Runs a test once per implementation of the minibatch step: the fused per-sample kernel and
+    the batched layer kernels (the library picks by batch size unless CCNN_MBGD_PATH says otherwise)."""
+    monkeypatch.setenv("CCNN_MBGD_PATH", request.param)
+    return request.param

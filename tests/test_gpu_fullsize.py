@@ -73,7 +73,7 @@ def test_config2_ksc_fp64_sgd_epoch_and_inference():
 
 
 @pytest.mark.parametrize("name,seed,counts", [("indian_pines", 20243, (8199, 2050)), ("pavia_u", 20244, (34220, 8556))])
-def test_config34_fp32_mbgd_b128_every_step_of_an_epoch(name, seed, counts):
+def test_config34_fp32_mbgd_b128_every_step_of_an_epoch(name, seed, counts, mbgd_path):
     z, onehot, tl, ref_train, ref_test, g_train, g_test = prepared(name, seed, 9, np.float32)
     T, B, lr = len(onehot), 128, np.float32(0.04)
     assert (T, len(tl)) == counts

@@ -185,7 +185,7 @@ def test_forward_chunked_large_batch():
 
 # --------------------------------------------------------------------------- MBGD
 @pytest.mark.parametrize("dtype,key,lr", [(np.float64, "mbgd64", 0.5), (np.float32, "mbgd32", 0.04)])
-def test_mbgd_golden(golden, dtype, key, lr):
+def test_mbgd_golden(golden, dtype, key, lr, mbgd_path):
     g = golden("train_small.npz")
     z = int(g["z"])
     cubes = dev(g["cubes"].astype(dtype))
@@ -207,7 +207,7 @@ def test_mbgd_golden(golden, dtype, key, lr):
                                           (np.float32, 224, 16, 0.04), (np.float32, 21, 5, 0.04),
                                           (np.float64, 448, 6, 0.5), (np.float32, 448, 3, 0.04),
                                           (np.float64, 60, 1, 0.5)])
-def test_mbgd_steps_match_oracle(dtype, z, B, lr):
+def test_mbgd_steps_match_oracle(dtype, z, B, lr, mbgd_path):
     steps = 3
     params, cubes, onehot = make_problem(z, B * steps, 7 + z, dtype)
     p_ref = params.copy()
@@ -226,8 +226,10 @@ def test_mbgd_steps_match_oracle(dtype, z, B, lr):
 
 
 @pytest.mark.parametrize("dtype,z,B,lr", [(np.float64, 176, 100, 0.5), (np.float32, 103, 128, 0.04),
-                                          (np.float32, 200, 50, 0.04), (np.float64, 30, 7, 0.5)])
-def test_mbgd_fused_step_matches_oracle(dtype, z, B, lr):
+                                          (np.float32, 200, 50, 0.04), (np.float64, 30, 7, 0.5),
+                                          (np.float32, 103, 700, 0.01), (np.float64, 60, 530, 0.5),
+                                          (np.float32, 224, 300, 0.01)])
+def test_mbgd_fused_step_matches_oracle(dtype, z, B, lr, mbgd_path):
     """ccnn_mbgd_step = gradient + the variant's own update in one call."""
     steps = 3
     params, cubes, onehot = make_problem(z, B * steps, 17 + z, dtype)
