@@ -358,22 +358,27 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
 
     constexpr int NWV = (PCHUNK * H / VW + 255) / 256;      // W1 vectors per thread per chunk
     constexpr int NPT = MS * PCHUNK / 256;               // pool elements per thread per chunk
-    V wreg[NWV];
-    T preg[NPT];
-    auto issue = [&](int c) {   // global loads of chunk c into registers (clamped, unconditional)
+    // Two register sets: while chunk c is multiplied, chunk c + 1 waits in one set and chunk c + 2's
+    // loads fly into the other, so a load has two multiply phases to arrive (with one set every
+    // chunk cost a full L2 round trip: the K loop was latency-bound).
+    struct ChunkRegs {
+        V w[NWV];
+        T p[NPT];
+    } ra, rb;
+    auto issue = [&](int c, ChunkRegs &rg) {   // global loads of chunk c into registers (clamped, unconditional)
         const int p0 = c * PCHUNK;
         const int pmax = min(PCHUNK, pout - p0);
         const int nvec = pmax * H / VW;
         const V *src = reinterpret_cast<const V *>(W1 + (long)p0 * H);
 #pragma unroll
-        for (int u = 0; u < NWV; u++) wreg[u] = src[min(u * 256 + tid, nvec - 1)];
+        for (int u = 0; u < NWV; u++) rg.w[u] = src[min(u * 256 + tid, nvec - 1)];
 #pragma unroll
         for (int u = 0; u < NPT; u++) {
             const int e = u * 256 + tid, b = e >> 6, p = e & 63;
-            preg[u] = pool[(long)(r0 + min(b, nb - 1)) * pout + p0 + min(p, pmax - 1)];
+            rg.p[u] = pool[(long)(r0 + min(b, nb - 1)) * pout + p0 + min(p, pmax - 1)];
         }
     };
-    auto commit = [&](int c) {   // registers -> LDS images of chunk c
+    auto commit = [&](int c, const ChunkRegs &rg) {   // registers -> LDS images of chunk c
         const int p0 = c * PCHUNK;
         const int pmax = min(PCHUNK, pout - p0);
         const int nvec = pmax * H / VW;
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
             const int e = u * 256 + tid;
             if (e < nvec) {
                 const int p = (e * VW) / H, n = e * VW - p * H;
-                *reinterpret_cast<V *>(wl + p * LDW1 + n) = wreg[u];
+                *reinterpret_cast<V *>(wl + p * LDW1 + n) = rg.w[u];
             }
         }
         if (pmax < PCHUNK)   // last chunk: rows past the end must read as zero
@@ -390,11 +395,12 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
 #pragma unroll
         for (int u = 0; u < NPT; u++) {
             const int e = u * 256 + tid, b = e >> 6, p = e & 63;
-            pt[b * LDP + p] = (b < nb && p < pmax) ? preg[u] : T(0);
+            pt[b * LDP + p] = (b < nb && p < pmax) ? rg.p[u] : T(0);
         }
     };
 
-    issue(0);   // first: the chunk's loads fly while the small operands below are staged
+    issue(0, ra);   // first: the chunk's loads fly while the small operands below are staged
+    if (nch > 1) issue(1, rb);
     stage<6, 256>(params + off_w2, H * O, tid, [&](int e, T v) { w2s[e] = v; });
     if (tid < H) b1s[tid] = params[off_b1 + tid];
     if (tid < O) b2s[tid] = params[off_b2 + tid];
@@ -413,11 +419,12 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
     // tile's epilogue used the region)
     for (int e = tid; e < PCHUNK * (LDW1 - H); e += 256) wl[(e / (LDW1 - H)) * LDW1 + H + e % (LDW1 - H)] = 0;
     __syncthreads();
-    commit(0);
+    commit(0, ra);
     FC_STAMP(1);
-    for (int c = 0; c < nch; c++) {
-        __syncthreads();                     // chunk c is in LDS
-        if (c + 1 < nch) issue(c + 1);       // next chunk's loads fly during the MFMAs
+    // chunk c is in LDS (it came from `cur`, which is free again), chunk c + 1 waits in `nxt`
+    auto chunk_step = [&](int c, ChunkRegs &cur, ChunkRegs &nxt) {
+        __syncthreads();                         // chunk c is in LDS
+        if (c + 2 < nch) issue(c + 2, cur);      // the loads of the chunk after next fly during two multiply phases
         for (int s = 0; s < PCHUNK / 4; s += 4) {
             T a[4], b[4][NJ];
 #pragma unroll
@@ -431,8 +438,12 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
 #pragma unroll
                 for (int j = 0; j < NJ; j++) acc[j] = Mma<T>::mma(a[u], b[u][j], acc[j]);
         }
-        __syncthreads();                     // everyone is done reading chunk c
-        if (c + 1 < nch) commit(c + 1);
+        __syncthreads();                         // everyone is done reading chunk c
+        if (c + 1 < nch) commit(c + 1, nxt);
+    };
+    for (int c = 0; c < nch; c += 2) {
+        chunk_step(c, ra, rb);
+        if (c + 1 < nch) chunk_step(c + 1, rb, ra);
     }
 
     FC_STAMP(2);
@@ -442,13 +453,20 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
     if (tile_next >= 0) {   // the next tile's first chunk flies during this tile's epilogue
         r0 = tile_next * MS;
         nb = min(MS, nrows - r0);
-        issue(0);
+        issue(0, ra);
+        if (nch > 1) issue(1, rb);
     }
+    // epilogue geometry: LS lanes per sample (8 with 32 samples, 16 with 16: every thread has work),
+    // lane jl producing outputs jl and jl + LS where they exist
+    constexpr int LS = 256 / MS;
+    const int jl = tid & (LS - 1), s = tid / LS;
+    const int o0 = min(jl, O - 1), o1 = min(jl + LS, O - 1);
+    const bool has0 = jl < O, has1 = jl + LS < O;
     int lab0 = 0, lab1 = 0;
     if (TRAIN) {   // this thread's two labels (clamped, unconditional): in flight during the activations
-        const int sl = min(tid >> 3, nb_done - 1), jl = tid & 7;
-        lab0 = tr.onehot[(long)(r0_done + sl) * O + jl];
-        lab1 = tr.onehot[(long)(r0_done + sl) * O + min(jl + 8, O - 1)];
+        const int sl = min(s, nb_done - 1);
+        lab0 = tr.onehot[(long)(r0_done + sl) * O + o0];
+        lab1 = tr.onehot[(long)(r0_done + sl) * O + o1];
     }
     T *z1s = wl;
 #pragma unroll
@@ -460,39 +478,33 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
         }
     }
     __syncthreads();
-    const int j8 = tid & 7;
-    const bool has_s = (tid >> 3) < MS;            // 8 lanes per sample: with 16 samples half the threads idle
-    const int s = has_s ? tid >> 3 : 0;
     T *zr = z1s + s * LDZ;
-    if (has_s)
-        for (int n = j8; n < H; n += 8) zr[n] = act(zr[n] + b1s[n]);   // gcn_mbgd_fp64.cu:302
+    for (int n = jl; n < H; n += LS) zr[n] = act(zr[n] + b1s[n]);   // gcn_mbgd_fp64.cu:302
     __syncthreads();
-    const int o0 = j8, o1 = j8 + 8;          // lane j8 produces outputs j8 and j8+8 (the latter for j8 < 5)
-    const bool has1 = o1 < O;
     T m0 = 0, m1 = 0;
-    for (int i = 0; i < H; i++) {
-        const T a = zr[i];
-        m0 = m0 + w2s[o0 + i * O] * a;
-        m1 = m1 + w2s[(has1 ? o1 : o0) + i * O] * a;
+    if (LS == 8) {
+        for (int i = 0; i < H; i++) {
+            const T a = zr[i];
+            m0 = m0 + w2s[o0 + i * O] * a;
+            m1 = m1 + w2s[o1 + i * O] * a;
+        }
+    } else {
+        for (int i = 0; i < H; i++) m0 = m0 + w2s[o0 + i * O] * zr[i];
     }
-    const T e0 = rexp(m0 + b2s[o0]), e1 = rexp(m1 + b2s[has1 ? o1 : o0]);
-    if (has_s) {
-        es[s * 16 + o0] = e0;
-        if (has1) es[s * 16 + o1] = e1;
-    }
+    const T e0 = rexp(m0 + b2s[o0]), e1 = rexp(m1 + b2s[o1]);
+    if (has0) es[s * 16 + o0] = e0;
+    if (has1) es[s * 16 + o1] = e1;
     __syncthreads();
     const T sum = tree13(es + s * 16);
     const T p0 = e0 / sum, p1 = e1 / sum;
-    if (has_s) {
-        ps[s * 16 + o0] = p0;
-        if (has1) ps[s * 16 + o1] = p1;
-    }
-    if (has_s && s < nb_done && probs) {
-        probs[(long)(r0_done + s) * O + o0] = p0;
+    if (has0) ps[s * 16 + o0] = p0;
+    if (has1) ps[s * 16 + o1] = p1;
+    if (s < nb_done && probs) {
+        if (has0) probs[(long)(r0_done + s) * O + o0] = p0;
         if (has1) probs[(long)(r0_done + s) * O + o1] = p1;
     }
     __syncthreads();
-    if (argmax && has_s && j8 == 0 && s < nb_done) {
+    if (argmax && jl == 0 && s < nb_done) {
         // count_err: running max starts at 0, strict '>' (gcn_mbgd_fp64.cu:636-647)
         T mx = 0;
         int idx = 0;
@@ -505,36 +517,41 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
     }
     if (TRAIN) {
         T *d2s = es;   // the exponentials are dead (every lane holds its probabilities in registers)
-        const bool live = has_s && s < nb_done;
+        const bool live = s < nb_done;
         const T dv0 = (p0 - lab0) / O, dv1 = (p1 - lab1) / O;   // gcn_mbgd_fp64.cu:352
-        if (has_s) {
-            d2s[s * 16 + o0] = dv0;
-            if (has1) d2s[s * 16 + o1] = dv1;
-        }
+        if (has0) d2s[s * 16 + o0] = dv0;
+        if (has1) d2s[s * 16 + o1] = dv1;
         if (live) {
-            tr.d2[(long)(r0_done + s) * O + o0] = dv0;
+            if (has0) tr.d2[(long)(r0_done + s) * O + o0] = dv0;
             if (has1) tr.d2[(long)(r0_done + s) * O + o1] = dv1;
+        }
+        // the loss terms (an exp and a log each) spread over the sample's lanes, from the labels already
+        // in registers; they go to the part of the W1 image that z1s does not use
+        T *lta = wl + MS * LDZ, *ltb = lta + MS * 16;
+        int *labs = reinterpret_cast<int *>(ltb + MS * 16);
+        if (has0) {
+            loss_terms(p0, lab0, &lta[s * 16 + o0], &ltb[s * 16 + o0]);
+            labs[s * 16 + o0] = lab0;
+        }
+        if (has1) {
+            loss_terms(p1, lab1, &lta[s * 16 + o1], &ltb[s * 16 + o1]);
+            labs[s * 16 + o1] = lab1;
         }
         __syncthreads();
         if (live) {
-            for (int n = j8; n < H; n += 8) {
+            T dd[O];
+#pragma unroll
+            for (int o = 0; o < O; o++) dd[o] = d2s[s * 16 + o];
+            for (int n = jl; n < H; n += LS) {
                 // bp_fully_connect(out -> hidden), gcn_mbgd_fp64.cu:416-434: 13-wide tree
                 T prod[O];
 #pragma unroll
-                for (int o = 0; o < O; o++) prod[o] = w2s[o + n * O] * d2s[s * 16 + o];
+                for (int o = 0; o < O; o++) prod[o] = w2s[o + n * O] * dd[o];
                 const T a = zr[n];
                 tr.a1[(long)(r0_done + s) * H + n] = a;
                 tr.d1[(long)(r0_done + s) * H + n] = tree13(prod) * (1 + a) * (1 - a);
             }
-            if (j8 == 7) {   // one lane per sample: the 13 loss terms and their ordered sum
-                T ta[O], tb[O];
-                int lab[O];
-                for (int o = 0; o < O; o++) {
-                    lab[o] = tr.onehot[(long)(r0_done + s) * O + o];
-                    loss_terms(ps[s * 16 + o], lab[o], &ta[o], &tb[o]);
-                }
-                tr.loss_values[r0_done + s] = loss_sum(ta, tb, lab);
-            }
+            if (jl == LS - 1) tr.loss_values[r0_done + s] = loss_sum(lta + s * 16, ltb + s * 16, labs + s * 16);   // the ordered sum
         }
     }
     FC_STAMP(3);

@@ -924,126 +924,6 @@ __global__ __launch_bounds__(CB_THREADS) void conv_bwd_batch(const T *__restrict
     if (wave == 0 && lane < F) out[F * K + lane] = bsum / re;
 }
 
-// The same product with the staging taken off the multiplying waves: a 12th wave alone moves the
-// next sample into the other LDS buffer (cube, zeroed delta image, scatter, bias-path sums) while
-// the 11 tile waves multiply the current one; one workgroup barrier per sample.  Used when two
-// buffers fit in LDS; conv_bwd_batch<T, 1> above is the fallback.
-constexpr int CS_THREADS = 64 * (CB_WAVES + 1);
-template <typename T>
-__global__ __launch_bounds__(CS_THREADS) void conv_bwd_staged(const T *__restrict__ cubes, long first,
-                                                              const T *__restrict__ dp, const T *__restrict__ pool,
-                                                              const unsigned char *__restrict__ px, int B,
-                                                              int cube_elems, int re, int mre, T *__restrict__ part)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const ConvBwdLds<T> L(re, mre);
-    T *base = reinterpret_cast<T *>(smem);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int col = lane & 15, kq = lane >> 4;
-    const int pout = F * mre, ks = (re + 3) >> 2, ldd = 4 * ks * LDWK;
-    const int G = gridDim.x;
-    T *out = part + (long)blockIdx.x * (F * K + F);
-    if ((int)blockIdx.x >= B) {   // no sample for this workgroup: its partial is zero
-        for (int e = tid; e < F * K + F; e += CS_THREADS) out[e] = 0;
-        return;
-    }
-    const int nsamp = (B - (int)blockIdx.x + G - 1) / G;   // samples blockIdx.x, + G, ..
-    if (wave == CB_WAVES) {
-        // ---- the staging wave
-        constexpr int NCR = (NB * CCNN_MAX_BANDS + 63) / 64;
-        constexpr int NPU = (F * ((((CCNN_MAX_BANDS - 20) / 2 + 1) + 1) / 2) + 63) / 64;
-        const int ncr = (cube_elems + 63) >> 6, npu = (pout + 63) >> 6;   // wave-uniform trip counts
-        T bsum = 0;   // lanes 0..19: bias path of filter `lane`, summed over the samples
-        for (int i = 0; i < nsamp; i++) {
-            const int b = blockIdx.x + i * G;
-            T *cube = base + (i & 1) * L.per_buf, *dl = cube + L.cube_len, *dps = dl + L.delta_len;
-            // loads first (clamped, unconditional, 16 in flight), zeroing while they fly
-            const T *src = cubes + (first + b) * (long)cube_elems;
-            typedef typename Vec16<T>::type V;
-            constexpr int VW = Vec16<T>::W;
-            for (int e = lane; e < L.delta_len / VW; e += 64) reinterpret_cast<V *>(dl)[e] = V{};
-            for (int e = cube_elems + lane; e < L.cube_len; e += 64) cube[e] = 0;
-#pragma unroll 1
-            for (int u0 = 0; u0 < ncr; u0 += 16) {
-                T t[16];
-#pragma unroll
-                for (int u = 0; u < 16; u++) t[u] = src[min((u0 + u) * 64 + lane, cube_elems - 1)];
-#pragma unroll
-                for (int u = 0; u < 16; u++) {
-                    const int e = (u0 + u) * 64 + lane;
-                    if (e < cube_elems) cube[e] = t[u];
-                }
-            }
-            wave_sync();   // the image is zero before this wave scatters into it
-#pragma unroll 1
-            for (int u0 = 0; u0 < npu; u0 += 8) {
-                T dv[8], pv[8];
-                unsigned bit[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int p = min((u0 + u) * 64 + lane, pout - 1);
-                    dv[u] = dp[(long)b * pout + p];
-                    pv[u] = pool[(long)b * pout + p];
-                    bit[u] = px[(long)b * pout + p];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int p = (u0 + u) * 64 + lane;
-                    if (p < pout) {
-                        const int f = p / mre, m = p - f * mre;
-                        dl[(f >> 4) * ldd + (2 * m + (int)bit[u]) * LDWK + (f & 15)] = dv[u];
-                        dps[p] = dv[u] * (1 + pv[u]) * (1 - pv[u]);
-                    }
-                }
-            }
-            wave_sync();
-            if (lane < F) {
-                T mid1 = 0;
-                for (int m = 0; m < mre; m++) mid1 = mid1 + dps[lane * mre + m];
-                bsum = bsum + mid1;
-            }
-            (void)NCR;
-            (void)NPU;
-            __syncthreads();   // sample i is staged (and the tile waves are done with sample i - 1)
-        }
-        __syncthreads();       // pairs with the tile waves' last barrier
-        if (lane < F) out[F * K + lane] = bsum / re;
-        return;
-    }
-    // ---- the 11 tile waves
-    typename Mma<T>::acc_t c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
-    __syncthreads();   // sample 0 staged
-    for (int i = 0; i < nsamp; i++) {
-        const T *cube = base + (i & 1) * L.per_buf, *dl = cube + L.cube_len;
-        const T *ap0 = dl + kq * LDWK + col, *ap1 = ap0 + ldd;
-        const T *bp = cube + WSTEP * kq + wave * 16 + col;
-        int s = 0;
-        for (; s + 2 <= ks; s += 2) {
-            const T a00 = ap0[4 * s * LDWK], a10 = ap1[4 * s * LDWK], b0 = bp[4 * s * WSTEP];
-            const T a01 = ap0[4 * (s + 1) * LDWK], a11 = ap1[4 * (s + 1) * LDWK], b1 = bp[4 * (s + 1) * WSTEP];
-            c0 = Mma<T>::mma(a00, b0, c0);
-            c1 = Mma<T>::mma(a10, b0, c1);
-            c0 = Mma<T>::mma(a01, b1, c0);
-            c1 = Mma<T>::mma(a11, b1, c1);
-        }
-        if (s < ks) {
-            const T a00 = ap0[4 * s * LDWK], a10 = ap1[4 * s * LDWK], b0 = bp[4 * s * WSTEP];
-            c0 = Mma<T>::mma(a00, b0, c0);
-            c1 = Mma<T>::mma(a10, b0, c1);
-        }
-        __syncthreads();   // done with sample i; sample i + 1 is staged
-    }
-    const int tap = wave * 16 + col;
-    if (tap < K) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int f0 = Mma<T>::row(lane, r), f1 = 16 + f0;
-            out[f0 * K + tap] = c0[r] / re;   // gcn_mbgd_fp64.cu:491
-            if (f1 < F) out[f1 * K + tap] = c1[r] / re;
-        }
-    }
-}
-
 // w -= lr * (sum over the S batch splits, in order) [/ divisor], or grad = that sum.
 template <typename T>
 __global__ void apply_partials(const T *__restrict__ part, int S, long stride, int n, T *__restrict__ grad,
@@ -1193,11 +1073,11 @@ int mbgd_batched(const T *params, const T *cubes, const int *onehot, long first,
     {
         const ConvBwdLds<T> L(d.re, d.mre);
         const bool two = L.bytes(2) <= 150 * 1024;
-        auto kern = two ? conv_bwd_staged<T> : conv_bwd_batch<T, 1>;
+        auto kern = two ? conv_bwd_batch<T, 2> : conv_bwd_batch<T, 1>;
         const size_t smem = L.bytes(two ? 2 : 1);
         if (int e = allow_smem(kern, smem)) return e;
-        launch("conv_bwd_batch", kern, dim3(G), dim3(two ? CS_THREADS : CB_THREADS), smem, st, cubes, first,
-               (const T *)w.dp, (const T *)w.pool, (const unsigned char *)w.px, B, d.cube, d.re, d.mre, w.slab);
+        launch("conv_bwd_batch", kern, dim3(G), dim3(CB_THREADS), smem, st, cubes, first, (const T *)w.dp,
+               (const T *)w.pool, (const unsigned char *)w.px, B, d.cube, d.re, d.mre, w.slab);
         CCNN_LAUNCH_CHECK();
     }
     const int S = batched_splits(B);
