@@ -44,6 +44,13 @@ def kernel_work(d, z):
         "grad_reduce": ("mfma", fc1 + 2.0 * 1300),
         "conv_pool_fwd": ("mfma", conv),
         "fc_head_fwd": ("mfma", fc1 + 2.0 * 1300),
+        # the batched training path: conv fwd | FC1 + FC2 fwd + delta1 | delta at the pooled features | conv gradient
+        "conv_pool_fwd_train": ("mfma", conv),
+        "fc_head_fwd_train": ("mfma", fc1 + 4.0 * 1300),
+        "dpool_bwd": ("mfma", fc1),
+        "conv_bwd_batch": ("mfma", conv),
+        # per launch: the batch splits read, the parameters read and written
+        "apply_partials": ("hbm", None),
         # 9z values read + 9z written + 9 int32 indices
         "gather_tile": ("hbm", 2.0 * 9 * z * 4 + 36),
         # per launch: read params, read gradient, write params
@@ -66,12 +73,179 @@ def committed_traffic(workload, batch, kernel):
     return None
 
 
+def kernel_rows(rep, d, z, pixels, passes=None, world=1, splits=1):
+    """Per-kernel table from the library's event timings: average duration, achieved rate on the
+    kernel's algorithmic work and its fraction of the peak that bounds it."""
+    work = kernel_work(d, z)
+    rows = {}
+    for name, (ms, cnt) in rep.items():
+        if name not in work or cnt == 0 or (work[name][1] is not None and name not in pixels):
+            continue
+        bound, per_px = work[name]
+        if per_px is None:
+            factor = {"allreduce_apply": 3.0 + 2.0 * world, "apply_partials": 2.0 + splits}.get(name, 3.0)
+            units = factor * d.nparams * 4 * cnt
+        else:
+            # a pass over n pixels may be several launches (the library works through its workspace in chunks)
+            units = per_px * pixels[name] * (passes.get(name, cnt) if passes else cnt)
+        tot_s = ms * 1e-3
+        if bound == "mfma":
+            ach, peak, unit = units / tot_s / 1e12, PEAK_FP32_MATRIX_TFLOPS, "TFLOP/s"
+        else:
+            ach, peak, unit = units / tot_s / 1e9, PEAK_HBM_GBS, "GB/s"
+        rows[name] = {"avg_us": round(ms / cnt * 1e3, 3), "launches": cnt, "bound": bound,
+                      "achieved": round(ach, 4), "peak": peak, "unit": unit, "frac": round(ach / peak, 5)}
+    return rows
+
+
+TRAIN_KERNELS = ("sample_fwd_bwd", "grad_reduce", "update_f32_kernel", "allreduce_apply", "conv_pool_fwd_train",
+                 "fc_head_fwd_train", "dpool_bwd", "conv_bwd_batch", "apply_partials")
+BATCHED_MIN_B = 768      # the library's choice between its two implementations of the step (mbgd.hip)
+
+
+def dominant(rows, workload, B):
+    train_k = [k for k in TRAIN_KERNELS if k in rows]
+    if not train_k:
+        return None
+    dom = max(train_k, key=lambda k: rows[k]["avg_us"])
+    k = rows[dom]
+    return {"kernel": dom, "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"], "unit": k["unit"],
+            "frac": k["frac"], "traffic": committed_traffic(workload, B, dom), "avg_us": k["avg_us"]}
+
+
+def timed_steps(fn, n):
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for i in range(n):
+        fn(i)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / n
+
+
+def train_rate(params_h, cubes, onehot_d, z, B, steps, workload, profile=True):
+    """fp32 MBGD steps of B samples over `cubes` (already on the device): pixels/s, and the
+    per-kernel table of the same steps.  The step size is scaled with 128/B (plain-sum update)."""
+    d = L.dims(z)
+    n = cubes.shape[0]
+    nb = n // B
+    if nb < 1:
+        return None
+    p = torch.from_numpy(params_h).to(cubes.device)
+    ws = ops.Workspace(cubes.device)
+    lv = torch.zeros((nb, B), dtype=torch.float64, device=cubes.device)
+    lr = 0.04 * min(1.0, 128.0 / B)
+
+    def step(i):
+        b = i % nb
+        ops.mbgd_step(p, cubes, onehot_d, b * B, B, z, lr, loss_values=lv[b], workspace=ws)
+    for i in range(min(steps, 30)):
+        step(i)
+    dt = timed_steps(step, steps)
+    assert torch.isfinite(p).all(), "training diverged"
+    out = {"batch": B, "train_pixels_per_s": round(B / dt, 1), "us_per_step": round(dt * 1e6, 2),
+           "path": "batched layer kernels" if B >= BATCHED_MIN_B else "fused per-sample kernel"}
+    if profile:
+        L.profile_enable(True)
+        psteps = min(steps, 100)
+        for i in range(psteps):
+            step(i)
+        torch.cuda.synchronize()
+        L.profile_enable(False)
+        rows = kernel_rows(L.profile_report(), d, z, {k: B for k in TRAIN_KERNELS},
+                           splits=min(16, max(1, (B + 255) // 256)))
+        out["roofline"] = dominant(rows, workload, B)
+        out["kernels"] = {k: {"avg_us": v["avg_us"], "frac": v["frac"]} for k, v in rows.items()}
+    return out
+
+
+def gather_call_rate(scene_d, idx_d, x, y, z, out, reps=5):
+    """The whole ccnn_gather call (ordering pass + tile kernel) on the list: algorithmic bytes
+    per second and the fraction of the HBM peak."""
+    gws = ops.Workspace(scene_d.device)
+    ops.gather(scene_d, idx_d, x, y, z, out=out, workspace=gws)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        ops.gather(scene_d, idx_d, x, y, z, out=out, workspace=gws)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / reps
+    n = idx_d.shape[0]
+    byts = n * (2.0 * 9 * z * 4 + 36)
+    return {"us_per_call": round(dt * 1e6, 1), "pixels": n, "achieved": round(byts / dt / 1e9, 1), "peak": PEAK_HBM_GBS,
+            "unit": "GB/s", "frac": round(byts / dt / 1e9 / PEAK_HBM_GBS, 4),
+            "what": "gather_keys + radix sort + gather_tile, wall clock of the whole call"}
+
+
+def workload_report(name, dev, full=True):
+    """Training (fp32 MBGD, B = 128 and 2048), whole-call gather and full-scene inference on one
+    scene shape, everything resident on the device; rank 0 only."""
+    x, y, z, nl = synth.SCENES[name]
+    d = L.dims(z)
+    rng = np.random.default_rng(SEED_BASE + WORKLOAD_CONFIG[name])
+    labels = synth.make_labels(x, y, nl, rng)
+    if name == "aviris":
+        # 939 M values: drawn on the device (3.8 GB in fp32), never on the host
+        g = torch.Generator(device=dev).manual_seed(SEED_BASE + WORKLOAD_CONFIG[name])
+        scene_d = torch.rand(x * y * z, generator=g, device=dev, dtype=torch.float32)
+    else:
+        scene_d = torch.from_numpy(synth.make_scene(x, y, z, np.float32, rng)).to(dev)
+    di = prep.scan_labels(labels, x, y)
+    tr9, te9, onehot, _ = prep.build_index(labels, di, x, y)
+    prep.shuffle(tr9, onehot, SEED_BASE)
+    params_h = prep.init_params(z, np.float32)
+    n_train = min(len(tr9), 65536)                  # a slice of the training list that fits comfortably
+    idx_d = torch.from_numpy(np.ascontiguousarray(tr9[:n_train])).to(dev)
+    cubes = torch.empty((n_train, 9 * z), dtype=torch.float32, device=dev)
+    out = {"scene": f"{x}x{y}x{z}", "labelled_pixels": int(len(di)), "train_pixels_used": int(n_train)}
+    out["gather_call"] = gather_call_rate(scene_d, idx_d, x, y, z, cubes)
+    oh_d = torch.from_numpy(np.ascontiguousarray(onehot[:n_train])).to(dev)
+    for B in (128, 2048):
+        r = train_rate(params_h, cubes, oh_d, z, B, 300 if B == 128 else 100, name, profile=False)
+        if r:
+            out[f"train_b{B}_pixels_per_s"] = r["train_pixels_per_s"]
+    del cubes, oh_d, idx_d
+    # every pixel of the scene classified straight from the scene (no cubes in memory)
+    all_lab = np.ones(x * y, dtype=np.float64)
+    a_tr9, a_te9, _, _ = prep.build_index(all_lab, prep.scan_labels(all_lab, x, y), x, y)
+    all_idx = torch.from_numpy(np.concatenate([a_tr9, a_te9])).to(dev)
+    del a_tr9, a_te9
+    p = torch.from_numpy(params_h).to(dev)
+    fws = ops.Workspace(dev)
+    ops.forward_scene(p, scene_d, all_idx, x, y, z, want_probs=False, workspace=fws)
+    reps = max(1, int(4e6 // all_idx.shape[0]))
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        ops.forward_scene(p, scene_d, all_idx, x, y, z, want_probs=False, workspace=fws)
+    torch.cuda.synchronize()
+    out["infer_full_scene_pixels_per_s"] = round(all_idx.shape[0] * reps / (time.perf_counter() - t), 1)
+    out["scene_pixels"] = int(all_idx.shape[0])
+    if name == "ksc":
+        # config 2: fp64 per-sample SGD (sequential by definition)
+        ns = 2048
+        idx64 = torch.from_numpy(np.ascontiguousarray(tr9[:ns])).to(dev)
+        c64 = ops.gather(scene_d.double(), idx64, x, y, z)
+        o64 = torch.from_numpy(np.ascontiguousarray(onehot[:ns])).to(dev)
+        p64 = torch.from_numpy(prep.init_params(z, np.float64)).to(dev)
+        sl = torch.zeros(1, dtype=torch.float64, device=dev)
+        sws = ops.Workspace(dev)
+        ops.sgd(p64, c64, o64, 0, 256, z, 0.008, sl, workspace=sws)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        ops.sgd(p64, c64, o64, 0, ns, z, 0.008, sl, workspace=sws)
+        torch.cuda.synchronize()
+        out["sgd_fp64_pixels_per_s"] = round(ns / (time.perf_counter() - t), 1)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="pavia_u", choices=["pavia_u", "indian_pines", "ksc"])
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip by_batch / by_workload (the other batch sizes and scene shapes, rank 0 only)")
     ap.add_argument("--batch", type=int, default=128, help="samples per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -250,7 +424,12 @@ def main():
     train_pps = world * B * args.steps / dt
     assert torch.isfinite(params).all(), "training diverged"
     replicas_identical = True
+    rank_devices = None
     if use_dist:
+        # which physical GPU every rank ran on (PCI bus id), as the group saw it
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, f"{torch.cuda.get_device_properties(local).name} "
+                                             f"pci {torch.cuda.get_device_properties(local).pci_bus_id:02x}")
         # every rank applied the same sums in the same order: the replicas must agree bit for bit
         digest = params.view(torch.int32).to(torch.int64).sum().reshape(1)
         every = [torch.empty_like(digest) for _ in range(world)]
@@ -369,32 +548,27 @@ def main():
             ops.gather(scene_d, idx_d, x, y, z, out=cubes, workspace=gws)
         torch.cuda.synchronize()
         L.profile_enable(False)
-        rep = L.profile_report()
-        work = kernel_work(d, z)
-        pixels = {"sample_fwd_bwd": B, "grad_reduce": B, "conv_pool_fwd": te_n, "fc_head_fwd": te_n,
-                  "gather_tile": slice_len}
-        for name, (ms, cnt) in rep.items():
-            if name not in work or cnt == 0:
+        pixels = {k: B for k in TRAIN_KERNELS}
+        pixels.update({"conv_pool_fwd": te_n, "fc_head_fwd": te_n, "gather_tile": slice_len})
+        kernels = kernel_rows(L.profile_report(), d, z, pixels, world=world,
+                              passes={"conv_pool_fwd": preps, "fc_head_fwd": preps, "gather_tile": preps})
+        roof = dominant(kernels, args.workload, B)
+        kernels["gather_call"] = gather_call_rate(scene_d, idx_d, x, y, z, cubes)
+
+    # ---- the other batch sizes (same cubes) and the other scene shapes, rank 0 only
+    by_batch, by_workload = None, None
+    if rank == 0 and world == 1 and not args.no_extras:
+        by_batch = []
+        for Bx in (128, 512, 2048):
+            r = train_rate(params_h, cubes, onehot_d, z, Bx, 300 if Bx < 2048 else 150, args.workload)
+            if r:
+                by_batch.append(r)
+        by_workload = {}
+        for name in ("ksc", "indian_pines", "pavia_u", "aviris"):
+            if name == args.workload:
                 continue
-            bound, per_px = work[name]
-            # a pass over te_n pixels may be several launches (the library works through its workspace in chunks)
-            passes = preps if name in ("conv_pool_fwd", "fc_head_fwd", "gather_tile") else cnt
-            per_launch = (3.0 + (2.0 * world if name == "allreduce_apply" else 0.0)) * d.nparams * 4
-            units = per_launch * cnt if per_px is None else per_px * pixels[name] * passes
-            tot_s = ms * 1e-3
-            if bound == "mfma":
-                ach, peak, unit = units / tot_s / 1e12, PEAK_FP32_MATRIX_TFLOPS, "TFLOP/s"
-            else:
-                ach, peak, unit = units / tot_s / 1e9, PEAK_HBM_GBS, "GB/s"
-            kernels[name] = {"avg_us": round(ms / cnt * 1e3, 3), "launches": cnt, "bound": bound,
-                             "achieved": round(ach, 4), "peak": peak, "unit": unit, "frac": round(ach / peak, 5)}
-        train_k = [k for k in ("sample_fwd_bwd", "grad_reduce", "update_f32_kernel", "allreduce_apply") if k in kernels]
-        if train_k:
-            dom = max(train_k, key=lambda k: kernels[k]["avg_us"])
-            k = kernels[dom]
-            roof = {"kernel": dom, "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"],
-                    "unit": k["unit"], "frac": k["frac"],
-                    "traffic": committed_traffic(args.workload, B, dom), "avg_us": k["avg_us"]}
+            by_workload[name] = workload_report(name, dev)
+            torch.cuda.empty_cache()
 
     # ---- CPU baseline: the oracle's fp32 minibatch step on the host cores (rank 0, N=1 only)
     cpu = None
@@ -434,7 +608,9 @@ def main():
                                     {"instep": "xgmi one-shot exchange inside the reduction kernel",
                                      "standalone": "xgmi one-shot exchange + update kernel after the gradient",
                                      "rccl": "rccl all-reduce + update"}[mode]),
-                       "exchange_calibration": calibration, "replicas_identical": replicas_identical},
+                       "exchange_calibration": calibration, "replicas_identical": replicas_identical,
+                       "ranks_in_group": (dist.get_world_size() if use_dist else 1),
+                       "backend": (dist.get_backend() if use_dist else None), "rank_devices": rank_devices},
             "infer_pixels_per_s": round(infer_pps, 1),
             "infer_from_scene_pixels_per_s": round(infer_scene_pps, 1),
             "infer_full_scene_pixels_per_s": round(infer_full_pps, 1),
@@ -443,7 +619,15 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
             "kernels": kernels,
+            "by_batch": by_batch,
+            "by_workload": by_workload,
         }
+        if by_workload is not None:
+            by_workload[args.workload] = {
+                "scene": f"{x}x{y}x{z}", "labelled_pixels": int(len(di)), "train_pixels_used": int(slice_len),
+                "gather_call": kernels.get("gather_call"), "train_b128_pixels_per_s": round(train_pps, 1) if B == 128 else None,
+                "train_b2048_pixels_per_s": next((r["train_pixels_per_s"] for r in (by_batch or []) if r["batch"] == 2048), None),
+                "infer_full_scene_pixels_per_s": round(infer_full_pps, 1), "scene_pixels": int(fs_n * world)}
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if comm is not None:
         comm.close()

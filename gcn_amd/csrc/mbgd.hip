@@ -937,10 +937,12 @@ __global__ void apply_partials(const T *__restrict__ part, int S, long stride, i
 }
 
 // ---------------------------------------------------------------------------
-// Which path a batch of B takes: the fused per-sample kernel is the faster one while a batch
-// fills the chip with at most one workgroup per CU; CCNN_MBGD_PATH=fused|batched overrides (tests
-// run both on the same inputs).
-constexpr int BATCHED_MIN_B = 256;
+// Which path a batch of B takes.  The fused per-sample kernel is a chain of latency-bound phases
+// that costs the same from 1 to 256 samples (one workgroup per CU) and then grows by the full
+// chain per 256 samples; the batched kernels have a floor twice as high and grow a quarter as
+// fast.  Measured crossovers: B = 640 (z = 103, fp32), 800 (z = 200, fp32), 580 (z = 176, fp64).
+// CCNN_MBGD_PATH=fused|batched overrides (tests run both on the same inputs).
+constexpr int BATCHED_MIN_B = 768;
 constexpr int BATCHED_MAX_PARTIALS = 256;   // workgroups (= partial gradient rows) of conv_bwd_batch
 constexpr int BATCHED_SPLIT_ROWS = 256;     // rows of the batch one grad_reduce split sums
 constexpr int BATCHED_MAX_SPLITS = 16;
