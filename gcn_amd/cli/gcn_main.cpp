@@ -6,15 +6,20 @@
 //
 // The reference compiles one trainer per binary; here the trainer is picked with
 // --variant=sgd_fp64|mbgd_fp64|mbgd_fp32 (default mbgd_fp32, what the reference's
-// shipped bin/gcn was built from); the four-argument form is the fp64 multi-GPU
-// trainer.  Options (all before the positional arguments):
+// shipped bin/gcn was built from); the four-argument form is the multi-GPU minibatch
+// trainer, fp64 like the reference's unless --variant=mbgd_fp32 is given.
+// The DataSet variable is streamed from the file through two pinned buffers straight into
+// every device's memory (never whole in host memory); each device gathers its own slice of the
+// training cubes from its own copy of the scene on a side stream, and the test cubes are
+// gathered there while training already runs.
+// Options (all before the positional arguments):
 //   --variant=V  --seed=N (default: time, like the reference)  --epochs=N (300)
 //   --batch=N (100)  --model=PATH (load weights instead of initialising)
 //   --exchange=rccl|oneshot (multi-GPU form: gradient exchange, default rccl)
 //   --tail=keep|drop (single GPU MBGD: train the last T % B samples as a short batch; default drop)
 //   --preprocess (write traindata.mat / testdata.mat like pre-treatment/preprocess048 and stop)
 //   --infer (skip training; needs --model)
-//   --mat-info=FILE, --mat-rewrite=SRC:DST   MAT-file utilities, no GPU needed
+//   --mat-info=FILE, --mat-rewrite=SRC:DST, --mat-stream=FILE:VAR[:CHUNK]   MAT-file utilities, no GPU needed
 // stdout keeps the reference's lines and spacing so tools/run.sh's field cuts work.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -59,6 +64,7 @@ double secs(Clock::time_point a) { return std::chrono::duration<double>(Clock::n
 
 struct Options {
     std::string variant = "mbgd_fp32", model;
+    bool variant_given = false;
     long seed = -1;
     int epochs = 300, batch = 100;
     bool infer = false, preprocess = false, keep_tail = false;
@@ -82,6 +88,10 @@ const Variant kMbgd32 = {"MBGD algo", false, true, 0.04, 0.001, 100.0,
                          {"filters", "bias0", "omega1", "bias1", "omega2", "bias2"}, "model/model.mat"};   // gcn_mbgd_fp32.cu:21-24
 const Variant kMgpu = {"MBGD algo", false, false, 0.5, 0.001, 1.0,
                        {"filters", "bias0", "omega1", "bias1", "omega2", "bias2"}, "model/model.mat"};     // hyper_version_mGPU_MBGD.cu:20-23
+// the same data-parallel driver around the fp32 trainer's arithmetic (gcn_mbgd_fp32.cu:21-24): no
+// reference file combines the two, its constants are the single-GPU fp32 trainer's
+const Variant kMgpu32 = {"MBGD algo", false, true, 0.04, 0.001, 100.0,
+                         {"filters", "bias0", "omega1", "bias1", "omega2", "bias2"}, "model/model.mat"};
 
 template <typename T>
 T *dmalloc(size_t n)
@@ -178,31 +188,136 @@ Samples build_samples(const std::vector<double> &labels, int x, int y, unsigned 
 template <typename T>
 struct Device {
     int id = 0;
-    hipStream_t st = nullptr;
-    T *cubes = nullptr, *params = nullptr, *grad = nullptr;
-    int *onehot = nullptr;
+    hipStream_t st = nullptr;    // training / testing
+    hipStream_t side = nullptr;  // scene upload and gathers
+    hipEvent_t train_ready = nullptr;
+    T *scene = nullptr, *cubes = nullptr, *params = nullptr, *grad = nullptr;
+    int *idx = nullptr, *onehot = nullptr;
     double *loss = nullptr;
-    void *ws = nullptr;
-    size_t ws_bytes = 0;
+    void *ws = nullptr, *gws = nullptr;
+    size_t ws_bytes = 0, gws_bytes = 0;
     long n_local = 0;
 };
 
+// The two precisions of the minibatch trainer behind one set of names.
 template <typename T>
-int gather_on(const T *scene, const int *idx, long n, int x, int y, int z, T *out, void *ws, size_t wsb);
+struct Api;
 template <>
-int gather_on<float>(const float *s, const int *i, long n, int x, int y, int z, float *o, void *ws, size_t wsb)
-{
-    return ccnn_gather_f32(s, i, n, x, y, z, o, ws, wsb, nullptr);
-}
+struct Api<float> {
+    static constexpr ncclDataType_t nccl = ncclFloat;
+    static int gather(const float *s, const int *i, long n, int x, int y, int z, float *o, void *ws, size_t wsb, hipStream_t st)
+    {
+        return ccnn_gather_f32(s, i, n, x, y, z, o, ws, wsb, st);
+    }
+    static int step(float *p, const float *c, const int *oh, long first, int B, int z, double lr, double *lv, void *ws,
+                    size_t wsb, hipStream_t st)
+    {
+        return ccnn_mbgd_step_f32(p, c, oh, first, B, z, (float)lr, lv, ws, wsb, st);
+    }
+    static int step_dp(ccnn_comm_t *cm, float *p, const float *c, const int *oh, long first, int B, int z, double lr,
+                       int /*global batch: the fp32 update is a plain sum*/, double *lv, void *ws, size_t wsb, hipStream_t st)
+    {
+        return ccnn_mbgd_step_dp_f32(cm, p, c, oh, first, B, z, (float)lr, lv, ws, wsb, st);
+    }
+    static int grad(const float *p, const float *c, const int *oh, long first, int B, int z, float *g, double *lv, void *ws,
+                    size_t wsb, hipStream_t st)
+    {
+        return ccnn_mbgd_grad_f32(p, c, oh, first, B, z, g, lv, nullptr, ws, wsb, st);
+    }
+    static int update(float *p, const float *g, double lr, int z, int, long, hipStream_t st)
+    {
+        return ccnn_update_f32(p, g, (float)lr, z, /*freeze_conv_bias=*/1, st);   // gcn_mbgd_fp32.cu:1052-1059
+    }
+    static int forward(const float *p, const float *c, long n, int z, int *am, void *ws, size_t wsb, hipStream_t st)
+    {
+        return ccnn_forward_f32(p, c, n, z, nullptr, am, ws, wsb, st);
+    }
+};
 template <>
-int gather_on<double>(const double *s, const int *i, long n, int x, int y, int z, double *o, void *ws, size_t wsb)
+struct Api<double> {
+    static constexpr ncclDataType_t nccl = ncclDouble;
+    static int gather(const double *s, const int *i, long n, int x, int y, int z, double *o, void *ws, size_t wsb, hipStream_t st)
+    {
+        return ccnn_gather_f64(s, i, n, x, y, z, o, ws, wsb, st);
+    }
+    static int step(double *p, const double *c, const int *oh, long first, int B, int z, double lr, double *lv, void *ws,
+                    size_t wsb, hipStream_t st)
+    {
+        return ccnn_mbgd_step_f64(p, c, oh, first, B, z, lr, lv, ws, wsb, st);
+    }
+    static int step_dp(ccnn_comm_t *cm, double *p, const double *c, const int *oh, long first, int B, int z, double lr,
+                       int global_batch, double *lv, void *ws, size_t wsb, hipStream_t st)
+    {
+        return ccnn_mbgd_step_dp_f64(cm, p, c, oh, first, B, z, lr, global_batch, lv, ws, wsb, st);
+    }
+    static int grad(const double *p, const double *c, const int *oh, long first, int B, int z, double *g, double *lv,
+                    void *ws, size_t wsb, hipStream_t st)
+    {
+        return ccnn_mbgd_grad_f64(p, c, oh, first, B, z, g, lv, nullptr, ws, wsb, st);
+    }
+    static int update(double *p, const double *g, double lr, int, int global_batch, long n, hipStream_t st)
+    {
+        return ccnn_update_f64(p, g, lr, global_batch, n, st);
+    }
+    static int forward(const double *p, const double *c, long n, int z, int *am, void *ws, size_t wsb, hipStream_t st)
+    {
+        return ccnn_forward_f64(p, c, n, z, nullptr, am, ws, wsb, st);
+    }
+};
+
+// DataSet from the file into every device's scene buffer: the values are read (inflated,
+// converted to T) a chunk at a time into one of two pinned host buffers while the other one's
+// copies are still in flight on the devices' side streams.  Host memory: the two buffers.
+template <typename T>
+void stream_scene(matio::Stream &ds, const std::vector<int> &ids, const std::vector<T *> &scene,
+                  const std::vector<hipStream_t> &side)
 {
-    return ccnn_gather_f64(s, i, n, x, y, z, o, ws, wsb, nullptr);
+    const size_t total = ds.numel();
+    size_t chunk = (size_t)(64u << 20) / sizeof(T);
+    if (const char *e = getenv("CCNN_SCENE_CHUNK"))   // elements per chunk (tests cross chunk boundaries with a small value)
+        if (atol(e) > 0) chunk = (size_t)atol(e);
+    if (chunk > total) chunk = total ? total : 1;
+    T *buf[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> ev[2];
+    for (int b = 0; b < 2; b++) {
+        CK(hipHostMalloc(reinterpret_cast<void **>(&buf[b]), chunk * sizeof(T), hipHostMallocDefault));
+        ev[b].resize(ids.size());
+        for (size_t k = 0; k < ids.size(); k++) {
+            CK(hipSetDevice(ids[k]));
+            CK(hipEventCreateWithFlags(&ev[b][k], hipEventDisableTiming));
+        }
+    }
+    std::string err;
+    size_t off = 0;
+    for (int i = 0; off < total; i++) {
+        const int b = i & 1;
+        const size_t n = total - off < chunk ? total - off : chunk;
+        if (i >= 2)
+            for (auto e : ev[b]) CK(hipEventSynchronize(e));   // the copies that last read this buffer are done
+        if (!ds.next(buf[b], n, err)) {
+            fprintf(stderr, "%s\n", err.c_str());
+            exit(EXIT_FAILURE);
+        }
+        for (size_t k = 0; k < ids.size(); k++) {
+            CK(hipSetDevice(ids[k]));
+            CK(hipMemcpyAsync(scene[k] + off, buf[b], n * sizeof(T), hipMemcpyHostToDevice, side[k]));
+            CK(hipEventRecord(ev[b][k], side[k]));
+        }
+        off += n;
+    }
+    for (int b = 0; b < 2; b++) {
+        for (size_t k = 0; k < ids.size(); k++) {
+            CK(hipSetDevice(ids[k]));
+            CK(hipEventSynchronize(ev[b][k]));
+            CK(hipEventDestroy(ev[b][k]));
+        }
+        CK(hipHostFree(buf[b]));
+    }
 }
 
 template <typename T>
-double run(const Options &opt, const Variant &v, const matio::Array &scene_a, const std::vector<double> &labels, int x,
-           int y, int z, const std::vector<int> &devices)
+double run(const Options &opt, const Variant &v, matio::Stream &ds, const std::vector<double> &labels, int x, int y, int z,
+           const std::vector<int> &devices)
 {
     const int nd = (int)devices.size();
     const bool multi = opt.pos.size() == 3;
@@ -211,10 +326,6 @@ double run(const Options &opt, const Variant &v, const matio::Array &scene_a, co
     CK(ccnn_get_dims(z, &d));
     const unsigned seed = opt.seed >= 0 ? (unsigned)opt.seed : (unsigned)time(NULL);
     Samples s = build_samples(labels, x, y, seed);
-
-    // scene in the trainer's precision (the fp32 reference reads a `single` DataSet, the others `double`)
-    std::vector<T> scene((size_t)x * y * z);
-    for (size_t i = 0; i < scene.size(); i++) scene[i] = scene_a.is_single ? (T)scene_a.f32[i] : (T)scene_a.f64[i];
 
     // weights: libc rand() continues from the shuffle, in the reference's draw order
     const int B = opt.batch;
@@ -230,57 +341,77 @@ double run(const Options &opt, const Variant &v, const matio::Array &scene_a, co
     }
     std::vector<T> params_t(params_h.begin(), params_h.end());
 
-    // gather on the first device (the reference gathers on the master, hyper_version_mGPU_MBGD.cu:856-857)
-    CK(hipSetDevice(devices[0]));
-    T *scene_d = to_device(scene);
-    int *tr_idx_d = to_device(s.train_idx9), *te_idx_d = to_device(s.test_idx9);
-    T *train_d = dmalloc<T>((size_t)s.n_train * d.cube), *test_d = dmalloc<T>((size_t)s.n_test * d.cube);
-    const size_t gws_bytes = ccnn_gather_workspace_bytes(s.n_train);   // sized for the larger list
-    void *gws = nullptr;
-    if (gws_bytes) CK(hipMalloc(&gws, gws_bytes));
-    CK(gather_on<T>(scene_d, tr_idx_d, s.n_train, x, y, z, train_d, gws, gws_bytes));
-    // the test list is already in pixel order: no ordering pass needed
-    CK(gather_on<T>(scene_d, te_idx_d, s.n_test, x, y, z, test_d, nullptr, 0));
-    CK(hipDeviceSynchronize());
-    if (gws) CK(hipFree(gws));
-    fprintf(stdout,
-            "[Samples prepared with %d Nearest-Neighbor-Pixels Strategy] Proportion of Training Samples: %d%%  Execution "
-            "time: %.3f sec\n",
-            8, 80, secs(t0));
-    CK(hipFree(scene_d));
-    CK(hipFree(tr_idx_d));
-    CK(hipFree(te_idx_d));
-
-    // per-device state; device k owns samples [k*floor(T/n), (k+1)*floor(T/n))
+    // device k owns samples [k*floor(T/n), (k+1)*floor(T/n)) (hyper_version_mGPU_MBGD.cu:934-940)
     const long slice = nd > 1 ? s.n_train / nd : s.n_train;
     const int sub_b = v.sgd ? 1 : B / nd;
     const long batch_num = v.sgd ? 0 : s.n_train / B;
     // --tail=keep (single GPU): the last T % B samples train as a short final batch averaged over its
     // own size (hyper_version_MBGD.cu:780, 794-796); default: dropped (gcn_mbgd_fp64.cu:895)
     const int tail = (!v.sgd && !multi && opt.keep_tail) ? (int)(s.n_train % B) : 0;
+
+    // Every device takes its own copy of the scene and gathers its own slice on its side stream
+    // (the reference gathers everything on the master and hands slices out through host memory,
+    // hyper_version_mGPU_MBGD.cu:856-857, 923-952: same cubes, no device-to-device copies).
     std::vector<Device<T>> dev(nd);
+    std::vector<T *> scene_ptrs(nd);
+    std::vector<hipStream_t> sides(nd);
     for (int k = 0; k < nd; k++) {
         Device<T> &D = dev[k];
         D.id = devices[k];
         CK(hipSetDevice(D.id));
         CK(hipStreamCreate(&D.st));
+        CK(hipStreamCreate(&D.side));
+        CK(hipEventCreateWithFlags(&D.train_ready, hipEventDisableTiming));
         D.n_local = slice;
-        if (k == 0) {
-            D.cubes = train_d;
-            D.onehot = to_device(s.onehot);
-        } else {
-            D.cubes = dmalloc<T>((size_t)slice * d.cube);
-            CK(hipMemcpyPeer(D.cubes, D.id, train_d + (size_t)k * slice * d.cube, devices[0],
-                             (size_t)slice * d.cube * sizeof(T)));
-            std::vector<int> oh(s.onehot.begin() + (size_t)k * slice * CCNN_CLASSES,
-                                s.onehot.begin() + (size_t)(k + 1) * slice * CCNN_CLASSES);
-            D.onehot = to_device(oh);
-        }
+        D.scene = dmalloc<T>((size_t)x * y * z);
+        D.cubes = dmalloc<T>((size_t)slice * d.cube);
+        std::vector<int> idx(s.train_idx9.begin() + (size_t)k * slice * 9, s.train_idx9.begin() + (size_t)(k + 1) * slice * 9);
+        D.idx = to_device(idx);
+        D.gws_bytes = ccnn_gather_workspace_bytes(slice);
+        if (D.gws_bytes) CK(hipMalloc(&D.gws, D.gws_bytes));
+        scene_ptrs[k] = D.scene;
+        sides[k] = D.side;
+    }
+    stream_scene<T>(ds, devices, scene_ptrs, sides);
+    ds.close();
+    // test cubes: on the first device's side stream, behind its training gather - they are not
+    // needed before the test loop, so the training steps below start without waiting for them
+    CK(hipSetDevice(dev[0].id));
+    int *te_idx_d = to_device(s.test_idx9);
+    T *test_d = dmalloc<T>((size_t)s.n_test * d.cube);
+    hipEvent_t test_ready;
+    CK(hipEventCreateWithFlags(&test_ready, hipEventDisableTiming));
+    for (int k = 0; k < nd; k++) {
+        Device<T> &D = dev[k];
+        CK(hipSetDevice(D.id));
+        CK(Api<T>::gather(D.scene, D.idx, slice, x, y, z, D.cubes, D.gws, D.gws_bytes, D.side));
+        CK(hipEventRecord(D.train_ready, D.side));
+        CK(hipStreamWaitEvent(D.st, D.train_ready, 0));
+    }
+    // the test gather is issued when the first training step has been queued (below): it then runs on
+    // the side stream beside the training kernels instead of in front of them
+    auto gather_test_cubes = [&]() {
+        CK(hipSetDevice(dev[0].id));
+        // the test list is already in pixel order: no ordering pass needed
+        CK(Api<T>::gather(dev[0].scene, te_idx_d, s.n_test, x, y, z, test_d, nullptr, 0, dev[0].side));
+        CK(hipEventRecord(test_ready, dev[0].side));
+    };
+    bool test_gather_issued = false;
+
+    // per-device training state, set up while the gathers run
+    for (int k = 0; k < nd; k++) {
+        Device<T> &D = dev[k];
+        CK(hipSetDevice(D.id));
+        std::vector<int> oh(s.onehot.begin() + (size_t)k * slice * CCNN_CLASSES,
+                            s.onehot.begin() + (size_t)(k + 1) * slice * CCNN_CLASSES);
+        D.onehot = to_device(oh);
         D.params = to_device(params_t);
         D.grad = dmalloc<T>(d.nparams);
         D.loss = dmalloc<double>(std::max<long>(batch_num + 1, 1) * std::max(sub_b, 1));
-        D.ws_bytes = v.sgd ? ccnn_sgd_workspace_bytes(z) : ccnn_mbgd_workspace_bytes(sub_b, z, (int)sizeof(T));
-        CK(hipMalloc(&D.ws, D.ws_bytes));
+        D.ws_bytes = v.sgd ? ccnn_sgd_workspace_bytes(z)
+                           : std::max(ccnn_mbgd_workspace_bytes(std::max(sub_b, 1), z, (int)sizeof(T)),
+                                      tail ? ccnn_mbgd_workspace_bytes(tail, z, (int)sizeof(T)) : (size_t)0);
+        CK(hipMalloc(&D.ws, D.ws_bytes ? D.ws_bytes : 1));
     }
     // Multi-GPU gradient exchange: RCCL all-reduce + update, or (--exchange=oneshot) the library's
     // one-kernel exchange over directly mapped peer buffers, fused with the update.
@@ -310,6 +441,11 @@ double run(const Options &opt, const Variant &v, const matio::Array &scene_a, co
         close(saved_stdout);
         NCK(init_rc);
     }
+    for (int k = 0; k < nd; k++) CK(hipEventSynchronize(dev[k].train_ready));
+    fprintf(stdout,
+            "[Samples prepared with %d Nearest-Neighbor-Pixels Strategy] Proportion of Training Samples: %d%%  Execution "
+            "time: %.3f sec\n",
+            8, 80, secs(t0));
 
     std::vector<double> logloss(300, 0.0);
     char head[96];
@@ -346,23 +482,21 @@ double run(const Options &opt, const Variant &v, const matio::Array &scene_a, co
                         if (nd > 1) CK(hipSetDevice(D.id));
                         double *lv = D.loss + i0 * sub_b;
                         if (!exchange) {
-                            if (v.f32)
-                                CK(ccnn_mbgd_step_f32((float *)D.params, (const float *)D.cubes, D.onehot, i0 * sub_b,
-                                                      sub_b, z, (float)lr, lv, D.ws, D.ws_bytes, D.st));
-                            else
-                                CK(ccnn_mbgd_step_f64((double *)D.params, (const double *)D.cubes, D.onehot, i0 * sub_b,
-                                                      sub_b, z, lr, lv, D.ws, D.ws_bytes, D.st));
+                            CK(Api<T>::step(D.params, D.cubes, D.onehot, i0 * sub_b, sub_b, z, lr, lv, D.ws, D.ws_bytes, D.st));
                         } else if (oneshot) {
                             // gradient, exchange with the other devices and update in two launches; the
                             // launches are asynchronous, so device k's kernel waits for its peers' while
                             // this loop goes on to start them
-                            CK(ccnn_mbgd_step_dp_f64(xch[k], (double *)D.params, (const double *)D.cubes, D.onehot,
-                                                     i0 * sub_b, sub_b, z, lr, B, lv, D.ws, D.ws_bytes, D.st));
+                            CK(Api<T>::step_dp(xch[k], D.params, D.cubes, D.onehot, i0 * sub_b, sub_b, z, lr, B, lv, D.ws,
+                                               D.ws_bytes, D.st));
                         } else {
-                            CK(ccnn_mbgd_grad_f64((const double *)D.params, (const double *)D.cubes, D.onehot,
-                                                  i0 * sub_b, sub_b, z, (double *)D.grad, lv, nullptr, D.ws,
-                                                  D.ws_bytes, D.st));
+                            CK(Api<T>::grad(D.params, D.cubes, D.onehot, i0 * sub_b, sub_b, z, D.grad, lv, D.ws, D.ws_bytes,
+                                            D.st));
                         }
+                    }
+                    if (!test_gather_issued) {   // the first step is queued: the test cubes are gathered beside the training
+                        gather_test_cubes();
+                        test_gather_issued = true;
                     }
                     if (oneshot) {
                         // nothing left to do: the step above exchanged and updated
@@ -371,24 +505,18 @@ double run(const Options &opt, const Variant &v, const matio::Array &scene_a, co
                         // (hyper_version_mGPU_MBGD.cu:962-978, 1093-1171)
                         NCK(ncclGroupStart());
                         for (int k = 0; k < nd; k++)
-                            NCK(ncclAllReduce(dev[k].grad, dev[k].grad, d.nparams, ncclDouble, ncclSum, comms[k], dev[k].st));
+                            NCK(ncclAllReduce(dev[k].grad, dev[k].grad, d.nparams, Api<T>::nccl, ncclSum, comms[k], dev[k].st));
                         NCK(ncclGroupEnd());
                         for (int k = 0; k < nd; k++) {
                             CK(hipSetDevice(dev[k].id));
-                            CK(ccnn_update_f64((double *)dev[k].params, (const double *)dev[k].grad, lr, B, d.nparams,
-                                               dev[k].st));
+                            CK(Api<T>::update(dev[k].params, dev[k].grad, lr, z, B, d.nparams, dev[k].st));
                         }
                     }
                 }
                 if (tail) {
                     Device<T> &D = dev[0];
                     double *lv = D.loss + batch_num * sub_b;
-                    if (v.f32)
-                        CK(ccnn_mbgd_step_f32((float *)D.params, (const float *)D.cubes, D.onehot, batch_num * sub_b, tail,
-                                              z, (float)lr, lv, D.ws, D.ws_bytes, D.st));
-                    else
-                        CK(ccnn_mbgd_step_f64((double *)D.params, (const double *)D.cubes, D.onehot, batch_num * sub_b,
-                                              tail, z, lr, lv, D.ws, D.ws_bytes, D.st));
+                    CK(Api<T>::step(D.params, D.cubes, D.onehot, batch_num * sub_b, tail, z, lr, lv, D.ws, D.ws_bytes, D.st));
                 }
                 // one D2H per device per epoch; host adds the per-sample losses in order
                 float loss32 = 0;
@@ -442,13 +570,20 @@ double run(const Options &opt, const Variant &v, const matio::Array &scene_a, co
 
     // test on the first device
     Clock::time_point t_test = Clock::now();
+    if (!test_gather_issued) gather_test_cubes();   // inference only, or per-sample SGD
+    CK(hipSetDevice(dev[0].id));
+    CK(hipEventSynchronize(test_ready));   // the test cubes were gathered on the side stream meanwhile
+    for (int k = 0; k < nd; k++) {          // nothing reads the scene copies any more
+        CK(hipSetDevice(dev[k].id));
+        CK(hipFree(dev[k].scene));
+        dev[k].scene = nullptr;
+    }
     CK(hipSetDevice(dev[0].id));
     int *argmax_d = dmalloc<int>(s.n_test), *count_d = dmalloc<int>(1), *tl_d = to_device(s.test_labels);
     const size_t fws_bytes = ccnn_forward_workspace_bytes(s.n_test, z, (int)sizeof(T));
     void *fws = nullptr;
     CK(hipMalloc(&fws, fws_bytes ? fws_bytes : 1));
-    if (v.f32) CK(ccnn_forward_f32((const float *)dev[0].params, (const float *)test_d, s.n_test, z, nullptr, argmax_d, fws, fws_bytes, dev[0].st));
-    else CK(ccnn_forward_f64((const double *)dev[0].params, (const double *)test_d, s.n_test, z, nullptr, argmax_d, fws, fws_bytes, dev[0].st));
+    CK(Api<T>::forward(dev[0].params, test_d, s.n_test, z, argmax_d, fws, fws_bytes, dev[0].st));
     CK(ccnn_count_correct(argmax_d, tl_d, s.n_test, count_d, dev[0].st));
     int right = 0;
     CK(hipMemcpyAsync(&right, count_d, sizeof(int), hipMemcpyDeviceToHost, dev[0].st));
@@ -472,7 +607,7 @@ double run(const Options &opt, const Variant &v, const matio::Array &scene_a, co
 // (:66-262): cubes of all labelled pixels in scan order (no shuffle), fp64, written as
 // testdata.mat {data (9z x test_size), labels (test_size x 1)} and
 // traindata.mat {data (9z x train_size), labels (13 x train_size, one-hot)}.
-int preprocess_dump(const matio::Array &scene_a, const std::vector<double> &labels, int x, int y, int z, int device)
+int preprocess_dump(matio::Stream &ds, const std::vector<double> &labels, int x, int y, int z, int device)
 {
     Clock::time_point t0 = Clock::now();
     ccnn_dims_t d;
@@ -480,10 +615,12 @@ int preprocess_dump(const matio::Array &scene_a, const std::vector<double> &labe
     Samples s = build_samples(labels, x, y, 0, false);
     fprintf(stdout, "train_size:%d  test_size:%d\n", s.n_train, s.n_test);
     fprintf(stdout, "Index computing completed!\n");
-    std::vector<double> scene((size_t)x * y * z);
-    for (size_t i = 0; i < scene.size(); i++) scene[i] = scene_a.is_single ? (double)scene_a.f32[i] : scene_a.f64[i];
     CK(hipSetDevice(device));
-    double *scene_d = to_device(scene);
+    double *scene_d = dmalloc<double>((size_t)x * y * z);
+    hipStream_t side;
+    CK(hipStreamCreate(&side));
+    stream_scene<double>(ds, {device}, {scene_d}, {side});
+    ds.close();
     std::vector<double> train((size_t)s.n_train * d.cube), test((size_t)s.n_test * d.cube);
     struct Part {
         const std::vector<int> *idx;
@@ -542,6 +679,48 @@ int mat_info(const std::string &src, const std::string &dst)
     return 0;
 }
 
+// `--mat-stream=FILE:VAR[:CHUNK]`: the streaming reader on one variable, CHUNK values at a time
+// as float (single arrays) or double; prints class, dimensions, sum and the peak resident set.
+int mat_stream(const std::string &spec)
+{
+    const size_t c1 = spec.find(':');
+    if (c1 == std::string::npos) {
+        fprintf(stderr, "--mat-stream=FILE:VAR[:CHUNK]\n");
+        return 1;
+    }
+    const size_t c2 = spec.find(':', c1 + 1);
+    const std::string file = spec.substr(0, c1), var = spec.substr(c1 + 1, c2 == std::string::npos ? c2 : c2 - c1 - 1);
+    const size_t chunk = c2 == std::string::npos ? (size_t)1 << 20 : (size_t)atol(spec.c_str() + c2 + 1);
+    matio::Stream st;
+    std::string err;
+    if (!st.open(file, var, err)) {
+        fprintf(stderr, "%s\n", err.c_str());
+        return 1;
+    }
+    double sum = 0;
+    std::vector<float> f32(st.is_single() ? chunk : 0);
+    std::vector<double> f64(st.is_single() ? 0 : chunk);
+    while (st.remaining()) {
+        const size_t n = st.remaining() < chunk ? st.remaining() : chunk;
+        if (!(st.is_single() ? st.next(f32.data(), n, err) : st.next(f64.data(), n, err))) {
+            fprintf(stderr, "%s\n", err.c_str());
+            return 1;
+        }
+        for (size_t i = 0; i < n; i++) sum += st.is_single() ? (double)f32[i] : f64[i];
+    }
+    long rss_kb = 0;
+    if (FILE *f = fopen("/proc/self/status", "r")) {
+        char line[256];
+        while (fgets(line, sizeof(line), f))
+            if (sscanf(line, "VmHWM: %ld kB", &rss_kb) == 1) break;
+        fclose(f);
+    }
+    printf("%s %s", var.c_str(), st.is_single() ? "single" : "double");
+    for (size_t dmn : st.dims()) printf(" %zu", dmn);
+    printf(" sum=%.17g peak_rss_kb=%ld\n", sum, rss_kb);
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char *argv[])
@@ -550,6 +729,7 @@ int main(int argc, char *argv[])
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         if (a.rfind("--mat-info=", 0) == 0) return mat_info(a.substr(11), "");
+        if (a.rfind("--mat-stream=", 0) == 0) return mat_stream(a.substr(13));
         if (a.rfind("--mat-rewrite=", 0) == 0) {
             const size_t c = a.find(':', 14);
             if (c == std::string::npos) {
@@ -558,7 +738,10 @@ int main(int argc, char *argv[])
             }
             return mat_info(a.substr(14, c - 14), a.substr(c + 1));
         }
-        if (a.rfind("--variant=", 0) == 0) opt.variant = a.substr(10);
+        if (a.rfind("--variant=", 0) == 0) {
+            opt.variant = a.substr(10);
+            opt.variant_given = true;
+        }
         else if (a.rfind("--seed=", 0) == 0) opt.seed = atol(a.c_str() + 7);
         else if (a.rfind("--epochs=", 0) == 0) opt.epochs = atoi(a.c_str() + 9);
         else if (a.rfind("--batch=", 0) == 0) opt.batch = atoi(a.c_str() + 8);
@@ -573,10 +756,15 @@ int main(int argc, char *argv[])
     if (const char *e = getenv("CCNN_SEED"))
         if (opt.seed < 0) opt.seed = atol(e);
     const bool multi = opt.pos.size() == 3;
-    const Variant *v = multi ? &kMgpu
+    const Variant *v = multi ? (!opt.variant_given || opt.variant == "mbgd_fp64" ? &kMgpu
+                                : opt.variant == "mbgd_fp32" ? &kMgpu32 : nullptr)
                              : opt.variant == "sgd_fp64" ? &kSgd
                              : opt.variant == "mbgd_fp64" ? &kMbgd64
                              : opt.variant == "mbgd_fp32" ? &kMbgd32 : nullptr;
+    if (!v && multi && opt.variant == "sgd_fp64") {
+        fprintf(stderr, "per-sample SGD is sequential: it has no multi-GPU form (use `gcn DATASET.mat device_id`)\n");
+        return 1;
+    }
     if (!v) {
         fprintf(stderr, "unknown --variant '%s' (sgd_fp64, mbgd_fp64, mbgd_fp32)\n", opt.variant.c_str());
         return 1;
@@ -635,28 +823,35 @@ int main(int argc, char *argv[])
         fprintf(stdout, "[Cube CNN training with %s] Training implemented on Device %d.\n", algo, dv);
     }
 
-    std::vector<matio::Array> arrs;
+    // labels whole (x*y doubles); DataSet is only opened here and streamed to the devices later
     std::string err;
-    if (!matio::read(opt.pos[0], {"DataSet", "labels"}, arrs, err)) {
+    matio::Stream lab, ds;
+    if (!lab.open(opt.pos[0], "labels", err) || !ds.open(opt.pos[0], "DataSet", err)) {
         fprintf(stderr, "%s\n", err.c_str());
         return 1;
     }
-    const matio::Array *scene = nullptr, *lab = nullptr;
-    for (auto &a : arrs) {
-        if (a.name == "DataSet") scene = &a;
-        if (a.name == "labels") lab = &a;
-    }
-    if (!scene || !lab || scene->dims.size() != 3 || lab->numel() != scene->dims[0] * scene->dims[1]) {
+    if (ds.dims().size() != 3 || lab.numel() != ds.dims()[0] * ds.dims()[1]) {
         fprintf(stderr, "'%s' must hold DataSet (x-by-y-by-z) and labels (x-by-y)\n", opt.pos[0].c_str());
         return 1;
     }
-    const int x = (int)scene->dims[0], y = (int)scene->dims[1], z = (int)scene->dims[2];
-    std::vector<double> labels(lab->numel());
-    for (size_t i = 0; i < labels.size(); i++) labels[i] = lab->is_single ? (double)lab->f32[i] : lab->f64[i];
+    // the kernels index pixels and planes with 32-bit integers: refuse what does not fit before narrowing
+    if (ds.dims()[0] > 0x7fffffffu || ds.dims()[1] > 0x7fffffffu || ds.dims()[2] > (size_t)CCNN_MAX_BANDS ||
+        ds.dims()[0] * ds.dims()[1] > 0x7fffffffu || ds.dims()[0] < 2 || ds.dims()[1] < 2) {
+        fprintf(stderr, "DataSet of %zu x %zu x %zu is outside what this build handles (2..2^31-1 pixels, at most %d bands)\n",
+                ds.dims()[0], ds.dims()[1], ds.dims()[2], CCNN_MAX_BANDS);
+        return 1;
+    }
+    const int x = (int)ds.dims()[0], y = (int)ds.dims()[1], z = (int)ds.dims()[2];
+    std::vector<double> labels(lab.numel());
+    if (!lab.next(labels.data(), labels.size(), err)) {
+        fprintf(stderr, "%s\n", err.c_str());
+        return 1;
+    }
+    lab.close();
 
-    if (opt.preprocess) return preprocess_dump(*scene, labels, x, y, z, devices[0]);
-    const double correct = v->f32 ? run<float>(opt, *v, *scene, labels, x, y, z, devices)
-                                  : run<double>(opt, *v, *scene, labels, x, y, z, devices);
+    if (opt.preprocess) return preprocess_dump(ds, labels, x, y, z, devices[0]);
+    const double correct = v->f32 ? run<float>(opt, *v, ds, labels, x, y, z, devices)
+                                  : run<double>(opt, *v, ds, labels, x, y, z, devices);
     fprintf(stdout, "Accuracy: %.3f%% \n", correct * 100);
     return 0;
 }

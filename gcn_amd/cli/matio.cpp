@@ -74,7 +74,7 @@ bool convert(const Cursor &c, const Tag &t, size_t count, std::vector<D> &dst)
 {
     auto run = [&](auto sample) {
         typedef decltype(sample) S;
-        if (t.nbytes < count * sizeof(S)) return false;
+        if (count > t.nbytes / sizeof(S)) return false;   // (no product that could wrap)
         dst.resize(count);
         const uint8_t *p = c.p + t.data;
         if (!c.swap && std::is_same<S, D>::value) {
@@ -113,7 +113,17 @@ bool parse_matrix(Cursor c, size_t begin, size_t end, const std::vector<std::str
     c.off = flags.next;
     if (!read_tag(c, dims) || dims.type != miINT32) { err = "malformed dimensions element"; return false; }
     Array a;
-    for (uint32_t i = 0; i < dims.nbytes / 4; i++) a.dims.push_back((size_t)(int32_t)c.u32(dims.data + 4 * i));
+    size_t total = 1;
+    for (uint32_t i = 0; i < dims.nbytes / 4; i++) {
+        const int32_t dv = (int32_t)c.u32(dims.data + 4 * i);
+        // sizes come from the file: a negative one, or a product that wraps, must not size a buffer
+        if (dv < 0 || (dv > 0 && total > (size_t)0x7fffffffffffull / (size_t)dv)) {
+            err = "array dimensions out of range";
+            return false;
+        }
+        total *= (size_t)dv;
+        a.dims.push_back((size_t)dv);
+    }
     c.off = dims.next;
     if (!read_tag(c, name) || (name.type != miINT8 && name.type != miUINT8 && name.type != miUTF8)) {
         err = "malformed array name";
@@ -203,6 +213,269 @@ bool read(const std::string &path, const std::vector<std::string> &names, std::v
     }
     return true;
 }
+
+// ---------------------------------------------------------------------------
+// streaming reader
+
+struct Stream::Impl {
+    FILE *f = nullptr;
+    bool swap = false;
+    // the element being walked: either `raw_left` bytes straight from the file, or a zlib stream
+    // fed from `comp_left` bytes of the file
+    bool compressed = false;
+    size_t raw_left = 0, comp_left = 0;
+    z_stream zs;
+    bool zs_live = false;
+    std::vector<uint8_t> in;      // compressed input window
+    std::vector<uint8_t> stage;   // values in their storage type, before conversion
+    uint32_t data_type = 0;       // mi* type of the data element
+    size_t data_left = 0;         // bytes of it not handed out yet
+
+    bool get(void *dst, size_t n)   // next n bytes of the current element
+    {
+        uint8_t *out = static_cast<uint8_t *>(dst);
+        if (!compressed) {
+            if (n > raw_left || std::fread(out, 1, n, f) != n) return false;
+            raw_left -= n;
+            return true;
+        }
+        zs.next_out = out;
+        while (n) {
+            if (zs.avail_in == 0) {
+                if (comp_left == 0) return false;
+                const size_t want = comp_left < in.size() ? comp_left : in.size();
+                if (std::fread(in.data(), 1, want, f) != want) return false;
+                comp_left -= want;
+                zs.next_in = in.data();
+                zs.avail_in = (uInt)want;
+            }
+            const uInt chunk = (uInt)(n > 0x40000000u ? 0x40000000u : n);
+            zs.avail_out = chunk;
+            const int rc = inflate(&zs, Z_NO_FLUSH);
+            n -= chunk - zs.avail_out;
+            if (rc == Z_STREAM_END && n) return false;
+            if (rc != Z_OK && rc != Z_STREAM_END) return false;
+        }
+        return true;
+    }
+    bool skip(size_t n)
+    {
+        uint8_t tmp[4096];
+        while (n) {
+            const size_t k = n < sizeof(tmp) ? n : sizeof(tmp);
+            if (!get(tmp, k)) return false;
+            n -= k;
+        }
+        return true;
+    }
+    uint32_t u32(const uint8_t *p) const
+    {
+        uint32_t v;
+        std::memcpy(&v, p, 4);
+        return swap ? __builtin_bswap32(v) : v;
+    }
+    // one sub-element tag: type, byte count, bytes of padding after the data; small elements
+    // carry their (at most 4) data bytes in `small`
+    bool tag(uint32_t &type, uint32_t &nbytes, size_t &pad, uint8_t small[4], bool &is_small)
+    {
+        uint8_t t[8];
+        if (!get(t, 8)) return false;
+        const uint32_t w0 = u32(t);
+        if (w0 >> 16) {
+            type = w0 & 0xffff;
+            nbytes = w0 >> 16;
+            if (nbytes > 4) return false;
+            std::memcpy(small, t + 4, 4);
+            is_small = true;
+            pad = 0;
+        } else {
+            type = w0;
+            nbytes = u32(t + 4);
+            is_small = false;
+            pad = (8 - nbytes % 8) % 8;
+        }
+        return true;
+    }
+    void end_element()
+    {
+        if (zs_live) {
+            inflateEnd(&zs);
+            zs_live = false;
+        }
+    }
+};
+
+Stream::Stream() : im_(new Impl) {}
+Stream::~Stream()
+{
+    close();
+    delete im_;
+}
+
+void Stream::close()
+{
+    im_->end_element();
+    if (im_->f) std::fclose(im_->f);
+    im_->f = nullptr;
+}
+
+bool Stream::open(const std::string &path, const std::string &name, std::string &err)
+{
+    close();
+    Impl &m = *im_;
+    m.f = std::fopen(path.c_str(), "rb");
+    if (!m.f) { err = "cannot open '" + path + "'"; return false; }
+    uint8_t hdr[128];
+    if (std::fread(hdr, 1, 128, m.f) != 128) { err = "'" + path + "' is not a MAT-file (too short)"; return false; }
+    if (std::memcmp(hdr, "MATLAB 7.3 MAT-file", 19) == 0) {
+        err = "'" + path + "' is a v7.3 (HDF5) MAT-file; save it with -v7 or -v6";
+        return false;
+    }
+    if (std::memcmp(hdr, "MATLAB 5.0 MAT-file", 19) != 0) { err = "'" + path + "' has no MAT-file header"; return false; }
+    if (hdr[126] == 'I' && hdr[127] == 'M') m.swap = false;
+    else if (hdr[126] == 'M' && hdr[127] == 'I') m.swap = true;
+    else { err = "bad endian indicator"; return false; }
+    m.in.resize(1 << 20);
+    for (;;) {
+        uint8_t t[8];
+        const long at = std::ftell(m.f);
+        if (std::fread(t, 1, 8, m.f) != 8) break;   // end of file: not found
+        const uint32_t type = m.u32(t), nbytes = m.u32(t + 4);
+        const long next = at + 8 + (long)nbytes + (type == miCOMPRESSED ? 0 : (long)((8 - nbytes % 8) % 8));
+        bool is_matrix = false;
+        if (type == miCOMPRESSED) {
+            m.compressed = true;
+            m.comp_left = nbytes;
+            std::memset(&m.zs, 0, sizeof(m.zs));
+            if (inflateInit(&m.zs) != Z_OK) { err = "zlib init failed"; return false; }
+            m.zs_live = true;
+            uint8_t inner[8];
+            if (m.get(inner, 8) && m.u32(inner) == miMATRIX) is_matrix = true;
+        } else if (type == miMATRIX) {
+            m.compressed = false;
+            m.raw_left = nbytes;
+            is_matrix = true;
+        }
+        if (is_matrix) {
+            uint32_t ty, nb;
+            size_t pad;
+            uint8_t small[4];
+            bool sm;
+            // array flags, dimensions, name
+            uint8_t flags[8];
+            bool ok = m.tag(ty, nb, pad, small, sm) && ty == miUINT32 && nb == 8 && !sm && m.get(flags, 8);
+            uint32_t cls = 0;
+            bool complex_ = false;
+            if (ok) {
+                const uint32_t f0 = m.u32(flags);
+                cls = f0 & 0xff;
+                complex_ = (f0 >> 11) & 1;
+            }
+            std::vector<size_t> dims;
+            size_t total = 1;
+            if (ok) ok = m.tag(ty, nb, pad, small, sm) && ty == miINT32 && nb % 4 == 0 && nb <= 64;
+            if (ok) {
+                uint8_t db[64 + 8];
+                if (sm) std::memcpy(db, small, 4);
+                else ok = m.get(db, nb + pad);
+                for (uint32_t i = 0; ok && i < nb / 4; i++) {
+                    const int32_t dv = (int32_t)m.u32(db + 4 * i);
+                    if (dv < 0 || (dv > 0 && total > (size_t)0x7fffffffffffull / (size_t)dv)) {
+                        err = "array dimensions out of range";
+                        return false;
+                    }
+                    total *= (size_t)dv;
+                    dims.push_back((size_t)dv);
+                }
+            }
+            std::string nm;
+            if (ok) ok = m.tag(ty, nb, pad, small, sm) && (ty == miINT8 || ty == miUINT8 || ty == miUTF8) && nb <= 4096;
+            if (ok) {
+                if (sm) {
+                    nm.assign(reinterpret_cast<const char *>(small), nb);
+                } else {
+                    std::vector<uint8_t> nbuf(nb + pad);
+                    ok = m.get(nbuf.data(), nb + pad);
+                    if (ok) nm.assign(reinterpret_cast<const char *>(nbuf.data()), nb);
+                }
+            }
+            if (ok && nm == name) {
+                if (cls < mxDOUBLE || cls > mxUINT64) { err = "variable '" + name + "' is not a numeric array"; return false; }
+                if (complex_) { err = "variable '" + name + "' is complex"; return false; }
+                if (!m.tag(ty, nb, pad, small, sm)) { err = "variable '" + name + "' has no data element"; return false; }
+                size_t esz = 0;
+                switch (ty) {
+                    case miDOUBLE: case miINT64: case miUINT64: esz = 8; break;
+                    case miSINGLE: case miINT32: case miUINT32: esz = 4; break;
+                    case miINT16: case miUINT16: esz = 2; break;
+                    case miINT8: case miUINT8: esz = 1; break;
+                    default: err = "variable '" + name + "': unsupported storage type"; return false;
+                }
+                dims_ = dims;
+                numel_ = dims.empty() ? 0 : total;
+                done_ = 0;
+                is_single_ = cls == mxSINGLE;
+                if (numel_ > nb / esz) { err = "variable '" + name + "': data element shorter than its dimensions"; return false; }
+                if (sm) {   // at most 4 bytes inline: serve them from the staging buffer
+                    err = "variable '" + name + "' is stored as a small element; use matio::read";
+                    return false;
+                }
+                m.data_type = ty;
+                m.data_left = (size_t)nb;
+                return true;
+            }
+        }
+        m.end_element();
+        if (std::fseek(m.f, next, SEEK_SET) != 0) break;
+    }
+    err = "'" + path + "' has no variable '" + name + "'";
+    return false;
+}
+
+template <typename D>
+bool Stream::next_impl(D *dst, size_t count, std::string &err)
+{
+    Impl &m = *im_;
+    if (count > remaining()) { err = "read past the end of the variable"; return false; }
+    auto run = [&](auto sample) {
+        typedef decltype(sample) S;
+        constexpr size_t CH = (4u << 20) / sizeof(S);
+        size_t left = count;
+        while (left) {
+            const size_t k = left < CH ? left : CH;
+            if (!m.swap && std::is_same<S, D>::value) {
+                if (!m.get(dst, k * sizeof(S))) return false;
+            } else {
+                m.stage.resize(k * sizeof(S));
+                if (!m.get(m.stage.data(), k * sizeof(S))) return false;
+                for (size_t i = 0; i < k; i++) dst[i] = (D)load_as<S>(m.stage.data() + i * sizeof(S), m.swap);
+            }
+            dst += k;
+            left -= k;
+        }
+        return true;
+    };
+    bool ok = false;
+    switch (m.data_type) {
+        case miDOUBLE: ok = run(double()); break;
+        case miSINGLE: ok = run(float()); break;
+        case miINT8: ok = run(int8_t()); break;
+        case miUINT8: ok = run(uint8_t()); break;
+        case miINT16: ok = run(int16_t()); break;
+        case miUINT16: ok = run(uint16_t()); break;
+        case miINT32: ok = run(int32_t()); break;
+        case miUINT32: ok = run(uint32_t()); break;
+        case miINT64: ok = run(int64_t()); break;
+        case miUINT64: ok = run(uint64_t()); break;
+        default: break;
+    }
+    if (!ok) { err = "truncated or corrupt data element"; return false; }
+    done_ += count;
+    return true;
+}
+
+bool Stream::next(float *dst, size_t count, std::string &err) { return next_impl(dst, count, err); }
+bool Stream::next(double *dst, size_t count, std::string &err) { return next_impl(dst, count, err); }
 
 bool write(const std::string &path, const std::vector<DoubleMatrix> &vars, std::string &err)
 {

@@ -32,6 +32,37 @@ struct Array {
 bool read(const std::string &path, const std::vector<std::string> &names, std::vector<Array> &out,
           std::string &err);
 
+// One numeric variable read front to back WITHOUT holding the file or the inflated element in
+// memory (a 2048 x 2048 x 224 DataSet is 7.5 GB as double): open() walks the top-level elements
+// (a compressed element is only inflated as far as its name), stops at the variable's data and
+// next() hands out the following `count` values, converted to T, through a bounded buffer.
+class Stream {
+public:
+    Stream();
+    ~Stream();
+    Stream(const Stream &) = delete;
+    Stream &operator=(const Stream &) = delete;
+    // false + err when the file cannot be read, is not MAT v5, or has no numeric real variable `name`
+    bool open(const std::string &path, const std::string &name, std::string &err);
+    const std::vector<size_t> &dims() const { return dims_; }
+    size_t numel() const { return numel_; }
+    bool is_single() const { return is_single_; }
+    size_t remaining() const { return numel_ - done_; }
+    // the next `count` values in storage (column-major) order; false + err past the end or on bad data
+    bool next(float *dst, size_t count, std::string &err);
+    bool next(double *dst, size_t count, std::string &err);
+    void close();
+
+private:
+    struct Impl;
+    Impl *im_;
+    std::vector<size_t> dims_;
+    size_t numel_ = 0, done_ = 0;
+    bool is_single_ = false;
+    template <typename D>
+    bool next_impl(D *dst, size_t count, std::string &err);
+};
+
 // Writes double matrices (uncompressed miMATRIX elements), in the given order.
 struct DoubleMatrix {
     std::string name;

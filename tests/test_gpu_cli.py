@@ -28,9 +28,10 @@ def make_dataset(tmp_path, dtype):
     return path, scene, labels
 
 
-def run_gcn(tmp_path, args):
+def run_gcn(tmp_path, args, env=None):
     assert os.path.exists(GCN), "build the CLI with __graft_entry__.build()"
-    r = subprocess.run([GCN] + args, cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    r = subprocess.run([GCN] + args, cwd=tmp_path, capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stderr
     return r.stdout
 
@@ -124,6 +125,22 @@ def test_multi_gpu_form_with_one_device(tmp_path, extra):
     B, epochs = 20, 2
     out = run_gcn(tmp_path, [f"--seed={SEED}", f"--epochs={epochs}", f"--batch={B}", *extra, path, "1", "0"])
     _, l_ref, acc_ref, _ = oracle_run(scene, labels, np.float64, B, 0.5, epochs)
+    losses, acc_line, _ = parse(out)
+    assert np.allclose(losses, l_ref, rtol=2e-5, atol=1e-6)
+    assert abs(float(acc_line.split(" ")[9].rstrip("%")) - 100 * acc_ref) <= 0.1 + 1e-9
+
+
+@pytest.mark.parametrize("extra", [[], ["--exchange=oneshot"]])
+def test_multi_gpu_form_fp32_with_one_device(tmp_path, extra):
+    """`gcn DATASET.mat 1 0 --variant=mbgd_fp32`: the data-parallel driver around the fp32 trainer's
+    arithmetic (plain-sum update, frozen conv bias, float loss accumulation) - with one device it
+    must reproduce the single-GPU fp32 trainer, through RCCL's route and through the exchange.  The
+    scene reaches the device in chunks of 1000 values here (the streaming upload crosses chunk ends)."""
+    path, scene, labels = make_dataset(tmp_path, np.float32)
+    B, epochs = 20, 2
+    out = run_gcn(tmp_path, ["--variant=mbgd_fp32", f"--seed={SEED}", f"--epochs={epochs}", f"--batch={B}", *extra, path, "1", "0"],
+                  env={"CCNN_SCENE_CHUNK": "1000"})
+    _, l_ref, acc_ref, _ = oracle_run(scene, labels, np.float32, B, 0.04, epochs, fifo=100.0)
     losses, acc_line, _ = parse(out)
     assert np.allclose(losses, l_ref, rtol=2e-5, atol=1e-6)
     assert abs(float(acc_line.split(" ")[9].rstrip("%")) - 100 * acc_ref) <= 0.1 + 1e-9
