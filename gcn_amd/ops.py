@@ -79,6 +79,35 @@ def gather(scene, idx9, x, y, z, out=None, workspace=None, sort=True):
     return out
 
 
+class GatherPlan:
+    """The order of one sample list, kept for repeated gathers of that list (other scenes, other
+    passes): `GatherPlan(idx9, x, y)` runs the ordering pass once; `plan.gather(scene, z)` only the
+    tile kernel.  Holds its own workspace; idx9 must stay alive and unchanged."""
+
+    def __init__(self, idx9, x, y):
+        _req(idx9, torch.int32, "idx9")
+        self.idx9, self.x, self.y = idx9, x, y
+        self.n = idx9.numel() // 9
+        if idx9.numel() != self.n * 9:
+            raise ValueError("idx9 must hold 9 indices per sample")
+        lib = _l.load()
+        nbytes = lib.ccnn_gather_workspace_bytes(self.n)
+        self.ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=idx9.device)
+        _l.check(lib.ccnn_gather_plan(_ptr(idx9), self.n, x, y, _ptr(self.ws), self.ws.numel(), _stream()),
+                 "ccnn_gather_plan")
+
+    def gather(self, scene, z, out=None):
+        sfx, _ = _sfx(scene.dtype)
+        _req(scene, scene.dtype, "scene", self.x * self.y * z)
+        if out is None:
+            out = torch.empty((self.n, 9 * z), dtype=scene.dtype, device=scene.device)
+        _req(out, scene.dtype, "out", self.n * 9 * z)
+        fn = getattr(_l.load(), f"ccnn_gather_planned_{sfx}")
+        _l.check(fn(_ptr(scene), _ptr(self.idx9), self.n, self.x, self.y, z, _ptr(out), _ptr(self.ws), self.ws.numel(),
+                    _stream()), f"ccnn_gather_planned_{sfx}")
+        return out
+
+
 def forward(params, cubes, z, want_probs=True, want_argmax=True, workspace=None):
     """Test-loop forward over cubes [n, 9z] -> (probs [n,13] | None, argmax int32 [n] | None)."""
     sfx, es = _sfx(params.dtype)

@@ -83,6 +83,19 @@ int ccnn_gather_f32(const float *scene, const int *idx9, long n, int x, int y, i
 int ccnn_gather_f64(const double *scene, const int *idx9, long n, int x, int y, int z,
                     double *out, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same gather for a sample list that is gathered more than once (several scenes with one
+ * label mask, repeated passes): ccnn_gather_plan does the ordering pass of ccnn_gather_* once and
+ * leaves the order in the workspace; ccnn_gather_planned_* then only runs the tile kernel.  The
+ * workspace (ccnn_gather_workspace_bytes(n) bytes) belongs to that idx9 list until it is planned
+ * again; the preprocessing / processing launches replaced are those of ccnn_gather_*.  Results
+ * are identical to ccnn_gather_*. */
+int ccnn_gather_plan(const int *idx9, long n, int x, int y, void *workspace, size_t workspace_bytes,
+                     void *stream);
+int ccnn_gather_planned_f32(const float *scene, const int *idx9, long n, int x, int y, int z,
+                            float *out, void *workspace, size_t workspace_bytes, void *stream);
+int ccnn_gather_planned_f64(const double *scene, const int *idx9, long n, int x, int y, int z,
+                            double *out, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Forward pass over n cubes: the test loop's convolution / maxpooling /
  * fully_connect / output_and_dvalue(false) launches plus the host count_err
  * argmax (gcn_mbgd_fp64.cu:1182-1231, 628-652; gcn_sgd_fp64.cu:941-983, 499-515).

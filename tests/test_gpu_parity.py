@@ -73,6 +73,23 @@ def test_gather_ragged_and_empty(dtype):
         assert out.tobytes() == orc.gather(scene, idx.reshape(-1, 9), x, y, z).tobytes()
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_gather_planned_equals_gather(dtype):
+    """One ordering pass, several gathers (two scenes with the same label mask, different band counts)."""
+    x, y = 37, 29
+    _, labels = synth.small_scene(x, y, 21, 5, dtype)
+    di = prep.scan_labels(labels, x, y)
+    tr9, _, oh, _ = prep.build_index(labels, di, x, y)
+    prep.shuffle(tr9, oh, 4)
+    for idx in (tr9, tr9[:16], tr9[:17], tr9[:0]):
+        idx_d = dev(np.ascontiguousarray(idx.reshape(-1, 9)))
+        plan = ops.GatherPlan(idx_d, x, y)
+        for z, seed in ((103, 1), (40, 2), (103, 3)):
+            scene = np.random.default_rng(seed).random(x * y * z).astype(dtype)
+            out = plan.gather(dev(scene), z).cpu().numpy()
+            assert out.tobytes() == orc.gather(scene, idx.reshape(-1, 9), x, y, z).tobytes(), (len(idx), z)
+
+
 def test_gather_full_size_property():
     """Indian-Pines-sized scene: gather equals plain indexing (a pure copy), checked on the device."""
     x, y, z, nl = synth.SCENES["indian_pines"]
