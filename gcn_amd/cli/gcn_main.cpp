@@ -473,6 +473,10 @@ double run(const Options &opt, const Variant &v, matio::Stream &ds, const std::v
                 CK(hipMemcpyAsync(&l, D.loss, sizeof(double), hipMemcpyDeviceToHost, D.st));
                 CK(hipStreamSynchronize(D.st));
                 single_rate = l / s.n_train;
+                if (single_rate != single_rate) {   // NaN: the kernel's workgroups lost each other, or the run diverged
+                    fprintf(stderr, "%s:%d: epoch %d: NaN loss, the parameters are not a valid model\n", __FILE__, __LINE__, iter + 1);
+                    exit(EXIT_FAILURE);
+                }
                 if (iter < 300) logloss[iter] = single_rate;
                 if (single_rate < v.min_err) break;   // before printing and scheduling (gcn_sgd_fp64.cu:860-861)
             } else {

@@ -64,6 +64,9 @@ inline int allow_smem(Kern k, size_t bytes)
     return bytes <= 64 * 1024 ? 0 : raise_smem_limit(reinterpret_cast<const void *>(k), bytes);
 }
 
+// Workgroups of `kernel` (threads, dynamic LDS bytes) the current device holds at once.
+int resident_blocks(const void *kernel, int threads, size_t smem);
+
 #define CCNN_LAUNCH_CHECK()                         \
     do {                                            \
         hipError_t e_ = hipGetLastError();          \

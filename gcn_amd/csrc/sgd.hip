@@ -227,7 +227,10 @@ __global__ __launch_bounds__(SGD_THREADS) void sgd_epoch(double *__restrict__ pa
                 zsum = zsum + __longlong_as_double((long long)((lo[g] & 0xffffffffull) | (hi[g] << 32)));
             z1[tid] = zsum;
         }
-        if (__syncthreads_or(aborted)) break;   // every wave of the workgroup leaves together
+        if (__syncthreads_or(aborted)) {        // every wave of the workgroup leaves together
+            aborted = true;
+            break;
+        }
         SGD_TICK(2);
 
         // ---- head, redundantly per workgroup: a1 (:289), softmax (:318-340), delta2 (:341), delta1 (:407)
@@ -348,7 +351,9 @@ __global__ __launch_bounds__(SGD_THREADS) void sgd_epoch(double *__restrict__ pa
         for (int e = tid; e < H * O; e += SGD_THREADS) params[d.off_w2 + e] = w2[e];
         if (tid < H) params[d.off_b1 + tid] = b1[tid];
         if (tid < O) params[d.off_b2 + tid] = b2[tid];
-        if (tid == 3 * 64 + 1) *loss = loss_acc;
+        // a workgroup that gave up waiting (never expected: see the residency check on the host)
+        // leaves a partly trained model behind: the loss says so instead of looking like a result
+        if (tid == 3 * 64 + 1) *loss = aborted ? __longlong_as_double(0x7ff8000000000000ll) : loss_acc;
     }
 }
 
@@ -382,6 +387,9 @@ int ccnn_sgd_f64(double *params, const double *cubes, const int *onehot, long fi
     const SgdLds L = sgd_lds(d);
     int rc = allow_smem(sgd_epoch, L.bytes);
     if (rc) return rc;
+    // the 20 worker workgroups wait for each other inside the launch: every workgroup of the grid
+    // must be resident at once (a device with masked or too few CUs cannot run this kernel)
+    if (resident_blocks(reinterpret_cast<const void *>(sgd_epoch), SGD_THREADS, L.bytes) < F * SGD_XCD_STRIDE) return CCNN_E_RANGE;
     launch("sgd_epoch", sgd_epoch, dim3(F * SGD_XCD_STRIDE), dim3(SGD_THREADS), L.bytes, st, params, cubes, onehot, first,
            count, d, lr, loss, ws);
     CCNN_LAUNCH_CHECK();

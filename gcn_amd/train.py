@@ -47,6 +47,8 @@ def fit_sgd(params, cubes, onehot, z, lr=0.008, min_err=0.0003, max_iter=300, lo
     for j in range(max_iter):
         ops.sgd(params, cubes, onehot, 0, n, z, lr, loss, workspace=ws)
         single_rate = loss.item() / n                     # one D2H per epoch (gcn_sgd_fp64.cu:857-858)
+        if single_rate != single_rate:                    # NaN: the kernel's workgroups lost each other (or the run diverged)
+            raise RuntimeError(f"epoch {j}: ccnn_sgd_f64 reported a NaN loss; the parameters are not a valid model")
         hist.loss.append(single_rate)
         hist.lr.append(lr)
         if single_rate < min_err:                         # checked before the schedule (:860-861)

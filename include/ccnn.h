@@ -132,7 +132,10 @@ int ccnn_count_correct(const int *argmax, const int *labels, long n, int *count,
  * scalar of output_and_loss (:343-365): zeroed when sample 0 is processed, then
  * decreased by sum(y log p + (1-y) log(1-p))/13 per sample.
  * workspace: ccnn_sgd_workspace_bytes(z) bytes; its contents carry state between
- * calls of one training run only in params and loss. */
+ * calls of one training run only in params and loss.  The kernel's 20 worker workgroups
+ * trade partial sums inside one launch, so the whole grid must be resident at once:
+ * CCNN_E_RANGE if the device cannot hold it; should a workgroup ever give up waiting
+ * (bounded wait), *loss comes back NaN and params are not a valid model. */
 size_t ccnn_sgd_workspace_bytes(int z);
 int ccnn_sgd_f64(double *params, const double *cubes, const int *onehot, long first, long count,
                  int z, double lr, double *loss, void *workspace, size_t workspace_bytes,
