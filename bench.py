@@ -282,6 +282,11 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
         args.gpus = world
+    # rehearsal on a box with fewer GPUs than ranks: CCNN_BENCH_DEVICE pins every rank to one device
+    # and CCNN_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU)
+    if os.environ.get("CCNN_BENCH_DEVICE"):
+        local = int(os.environ["CCNN_BENCH_DEVICE"])
+    backend = os.environ.get("CCNN_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     use_dist = world > 1 or args.force_dist
     if use_dist:
@@ -290,8 +295,19 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     L.load()
+    t_start = time.perf_counter()
+    if os.environ.get("CCNN_BENCH_TRACE_AFTER"):   # rehearsals: where is a rank that stopped making progress?
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["CCNN_BENCH_TRACE_AFTER"]), exit=False, file=sys.stderr)
+
+    def log(msg):
+        # progress on stderr: a long run must not look hung to whoever watches it
+        print(f"[bench rank {rank} +{time.perf_counter() - t_start:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
     # ---- synthetic scene of the real scene's shape, prepared exactly like training() does
     x, y, z, nl = synth.SCENES[args.workload]
@@ -322,6 +338,7 @@ def main():
     ws = ops.Workspace(dev)
     lr = 0.04 / world      # plain-sum update: keep the step size independent of the global batch
 
+    log(f"inputs resident: {slice_len} training cubes, {te_n} test cubes")
     # N>1: the library's one-shot exchange over xGMI, fused with the update; RCCL if it cannot be
     # set up on this node or fails its self-test against RCCL (CCNN_ALLREDUCE=rccl forces RCCL)
     comm = None
@@ -341,6 +358,7 @@ def main():
     # route of the N>1 step: "instep" (exchange inside the reduction kernel), "standalone" (gradient,
     # then the library's exchange + update kernel) or "rccl" (gradient, RCCL all-reduce, update)
     mode = "instep" if comm is not None else "rccl"
+    log(f"exchange set up: mode {mode}" + (f", ranks share a device: {comm.shared_device}" if comm is not None else ""))
 
     def step(i):
         b = i % nb
@@ -394,6 +412,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
+    log("warm-up done")
     calibration = None
     if comm is not None and mode == "rccl":
         comm.close()
@@ -437,8 +456,10 @@ def main():
         for i in range(args.warmup):
             step(i)
         fence()
+    log(f"timing {args.steps} steps, mode {mode}")
     dt = timed(args.steps, args.warmup)
     train_pps = world * B * args.steps / dt
+    log(f"timed region done: {dt / args.steps * 1e6:.2f} us/step")
     assert torch.isfinite(params).all(), "training diverged"
     replicas_identical = True
     rank_devices = None
@@ -505,6 +526,7 @@ def main():
     infer_full_pps = world * fs_n * fs_reps / dtf
     del all_idx_d
 
+    log("inference timed")
     # ---- fp64 per-sample SGD on the same cubes (sequential by definition: replicas only, rank 0 reports)
     sgd_pps = None
     if rank == 0:
@@ -572,6 +594,7 @@ def main():
         roof = dominant(kernels, args.workload, B)
         kernels["gather_call"] = gather_call_rate(scene_d, idx_d, x, y, z, cubes)
 
+    log("per-kernel timing done")
     # ---- the other batch sizes (same cubes) and the other scene shapes, rank 0 only
     by_batch, by_workload = None, None
     if rank == 0 and world == 1 and not args.no_extras:
@@ -580,12 +603,14 @@ def main():
             r = train_rate(params_h, cubes, onehot_d, z, Bx, 300 if Bx < 2048 else 150, args.workload)
             if r:
                 by_batch.append(r)
+            log(f"batch {Bx} done")
         by_workload = {}
         for name in ("ksc", "indian_pines", "pavia_u", "aviris"):
             if name == args.workload:
                 continue
             by_workload[name] = workload_report(name, dev)
             torch.cuda.empty_cache()
+            log(f"workload {name} done")
 
     # ---- CPU baseline: the oracle's fp32 minibatch step on the host cores (rank 0, N=1 only)
     cpu = None
