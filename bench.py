@@ -373,7 +373,12 @@ def main():
             if mode == "standalone":
                 comm.allreduce_update(params, grad, lr, z)
             else:
-                dist.all_reduce(grad)
+                if backend == "gloo":   # rehearsal backend: gloo reduces host tensors
+                    h = grad.cpu()
+                    dist.all_reduce(h)
+                    grad.copy_(h)
+                else:
+                    dist.all_reduce(grad)
                 ops.update(params, grad, lr, z)
 
     def fence():
