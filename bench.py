@@ -193,6 +193,32 @@ def gather_call_rate(scene_d, idx_d, x, y, z, out, reps=5):
                          "what": "ccnn_gather_f32: ordering pass (gather_keys + radix sort) + tile kernel on every call"}}
 
 
+def gather_fully_labelled(scene_d, x, y, z, reps=5):
+    """Every pixel of the scene labelled and gathered in shuffled order through one plan (the plan
+    picks the tile kernel for such a list): wall clock of the whole call."""
+    rng = np.random.default_rng(SEED_BASE + 99)
+    labels = rng.integers(1, 14, x * y).astype(np.int32)
+    di = prep.scan_labels(labels, x, y)
+    tr9, te9, _, _ = prep.build_index(labels, di, x, y)
+    idx = np.concatenate([tr9.reshape(-1, 9), te9.reshape(-1, 9)])
+    idx = idx[rng.permutation(len(idx))][: (4 << 30) // (9 * z * 4)]      # at most 4 GiB of cubes
+    idx_d = torch.from_numpy(np.ascontiguousarray(idx)).to(scene_d.device)
+    out = torch.empty((len(idx), 9 * z), dtype=torch.float32, device=scene_d.device)
+    plan = ops.GatherPlan(idx_d, x, y)
+    plan.gather(scene_d, z, out=out)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        plan.gather(scene_d, z, out=out)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / reps
+    byts = len(idx) * (2.0 * 9 * z * 4 + 36)
+    return {"pixels": int(len(idx)), "kernel": "gather_dense (tiles)" if plan.dense else "gather_tile (ordered list)",
+            "us_per_call": round(dt * 1e6, 1), "achieved": round(byts / dt / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(byts / dt / 1e9 / PEAK_HBM_GBS, 4),
+            "what": "ccnn_gather_planned_f32 over every pixel of the scene, wall clock of the whole call"}
+
+
 def workload_report(name, dev, full=True):
     """Training (fp32 MBGD, B = 128 and 2048), whole-call gather and full-scene inference on one
     scene shape, everything resident on the device; rank 0 only."""
@@ -609,6 +635,7 @@ def main():
             if r:
                 by_batch.append(r)
             log(f"batch {Bx} done")
+        kernels["gather_call"]["fully_labelled"] = gather_fully_labelled(scene_d, x, y, z)
         by_workload = {}
         for name in ("ksc", "indian_pines", "pavia_u", "aviris"):
             if name == args.workload:

@@ -12,7 +12,9 @@
 // The training list is shuffled, so with a workspace the samples are first ordered
 // by centre pixel (radix sort of n keys) purely to decide which 8 samples share a
 // workgroup; each cube still lands at its own row i of `out`.
+#include <cstdlib>
 #include <cstring>
+#include <new>
 
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
@@ -241,7 +243,195 @@ int gather_impl(const T *scene, const int *idx9, long n, int x, int y, int z, T 
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Dense path: lists whose samples are plain 3x3 neighbourhoods (mirrored at the scene's edge, as
+// ccnn_host_build_index makes them) and cover a good share of the tiles they touch - fully or
+// densely labelled scenes.  No sort: one scatter builds a pixel -> sample-row table (head[] /
+// next[] chains, so a pixel that occurs twice in the list is served twice) and the list of
+// non-empty 32 x 8 pixel tiles; the gather kernel then stages each tile plus a one-pixel halo,
+// DB bands at a time, ONCE in LDS (coalesced row reads; every scene value is fetched once per
+// tile instead of nine times) and writes every sample's [DB][9] run from there.
+constexpr int DTX = 32, DTY = 8;                 // tile: 32 pixels along x (contiguous in memory) x 8 along y
+constexpr int DRX = DTX + 2, DRY = DTY + 2;      // with halo
+constexpr int DREG = DRX * DRY;                  // region cells per band
+constexpr long DENSE_MIN_SAMPLES = 65536;
+template <typename T>
+struct DenseCfg {
+    static constexpr int VW = 16 / (int)sizeof(T);    // values per 16-byte store
+    static constexpr int DB = 7 * VW;                 // bands per pass: [DB][9] is 63 lanes x 16 bytes; 38 KB of LDS
+};
+// 16 bytes of a sample's run: rows start on 4- or 8-byte boundaries only, the store is one
+// unaligned dwordx4 all the same
+template <typename T>
+union Run16 {
+    T v[16 / sizeof(T)];
+    __attribute__((ext_vector_type(4))) int bits;
+};
+// (the compiler splits a store it believes unaligned into dwordx3 + dword; the hardware takes
+// the dwordx4 at any 4-byte boundary)
+__device__ __forceinline__ void store16_unaligned(void *dst, __attribute__((ext_vector_type(4))) int bits)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(dst), "v"(bits) : "memory");
+}
+
+struct DenseWs {
+    int *head, *next, *tile_count, *tiles, *counters;   // counters: [0] non-empty tiles, [1] samples that are not plain neighbourhoods
+    static size_t bytes(long n, int x, int y)
+    {
+        const long nt = (long)((x + DTX - 1) / DTX) * ((y + DTY - 1) / DTY);
+        return align_up((size_t)x * y * sizeof(int)) + align_up((size_t)n * sizeof(int)) + 2 * align_up((size_t)nt * sizeof(int)) +
+               align_up(16 * sizeof(int));
+    }
+    DenseWs(void *ws, long n, int x, int y)
+    {
+        const long nt = (long)((x + DTX - 1) / DTX) * ((y + DTY - 1) / DTY);
+        Carver c(ws);
+        head = c.take<int>((size_t)x * y);
+        next = c.take<int>(n);
+        tile_count = c.take<int>(nt);
+        tiles = c.take<int>(nt);
+        counters = c.take<int>(16);
+    }
+};
+
+__device__ __forceinline__ int mirror(int v, int d, int lim) { return (v + d < 0 || v + d >= lim) ? v - d : v + d; }
+
+__global__ void dense_build(const int *__restrict__ idx9, long n, int x, int y, DenseWs w)
+{
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int row[NB];
+#pragma unroll
+    for (int j = 0; j < NB; j++) row[j] = idx9[i * NB + j];
+    const int p = row[NB / 2];
+    bool plain = p >= 0 && p < x * y;
+    const int r = plain ? p % x : 0, c = plain ? p / x : 0;
+#pragma unroll
+    for (int j = 0; j < NB; j++) plain = plain && row[j] == mirror(r, j % 3 - 1, x) + mirror(c, j / 3 - 1, y) * x;
+    if (!plain) {
+        atomicAdd(&w.counters[1], 1);
+        return;
+    }
+    w.next[i] = atomicExch(&w.head[p], (int)i);
+    const int t = (c / DTY) * ((x + DTX - 1) / DTX) + r / DTX;
+    if (atomicAdd(&w.tile_count[t], 1) == 0) w.tiles[atomicAdd(&w.counters[0], 1)] = t;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gather_dense(const T *__restrict__ scene, int x, int y, int z, long plane,
+                                                    DenseWs w, T *__restrict__ out)
+{
+    constexpr int DB = DenseCfg<T>::DB;
+    __shared__ T reg[DB * DREG];
+    __shared__ int shead[DTX * DTY], snext[DTX * DTY];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntx = (x + DTX - 1) / DTX;
+    const int t = w.tiles[blockIdx.x];
+    const int tx0 = (t % ntx) * DTX, ty0 = (t / ntx) * DTY;
+    const long cube_len = (long)NB * z;
+    // this thread's pixel of the tile: head of its chain and the second link (both -1 for most pixels)
+    {
+        const int px = tid % DTX, py = tid / DTX;
+        const int r = tx0 + px, c = ty0 + py;
+        int h = -1, nx = -1;
+        if (r < x && c < y) h = w.head[c * x + r];
+        if (h >= 0) nx = w.next[h];
+        shead[tid] = h;
+        snext[tid] = nx;
+    }
+    const int b0 = blockIdx.y * DB;
+    const int nb = min(DB, z - b0);
+    // the tile with its halo, nb bands: rows of 34 contiguous values (clamped at the scene's edge:
+    // cells outside the scene are never read, neighbours are mirrored about the centre pixel)
+    const int cells = nb * DREG;
+    for (int e0 = 0; e0 < cells; e0 += 16 * 256) {
+        T v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int e = min(e0 + u * 256 + tid, cells - 1);
+            const int b = e / DREG, rem = e - b * DREG;
+            const int ry = rem / DRX, rx = rem - ry * DRX;
+            const int gx = min(max(tx0 - 1 + rx, 0), x - 1), gy = min(max(ty0 - 1 + ry, 0), y - 1);
+            v[u] = scene[(long)(b0 + b) * plane + (long)gy * x + gx];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int e = e0 + u * 256 + tid;
+            if (e < cells) reg[e] = v[u];
+        }
+    }
+    __syncthreads();
+    // Each wave serves whole pixels; lane l < 63 holds the run's values VW l .. VW l + VW - 1, each
+    // with a fixed (band, neighbour) whatever the pixel is, and writes them with one 16-byte store.
+    constexpr int VW = DenseCfg<T>::VW;
+    int kb[VW], kdr[VW], kdc[VW];
+#pragma unroll
+    for (int i = 0; i < VW; i++) {
+        const int k = min(VW * lane + i, DB * NB - 1), j = k % NB;
+        kb[i] = (k / NB) * DREG;
+        kdr[i] = j % 3 - 1;
+        kdc[i] = j / 3 - 1;
+    }
+    const int run = nb * NB;
+    const int have = min(max(run - VW * lane, 0), VW);      // this lane's values inside the run
+    for (int pix = wave; pix < DTX * DTY; pix += 4) {
+        int rowi = shead[pix];
+        if (rowi < 0) continue;                    // wave-uniform: no sample at this pixel
+        const int r = tx0 + pix % DTX, c = ty0 + pix / DTX;
+        Run16<T> val;
+#pragma unroll
+        for (int i = 0; i < VW; i++) {
+            const int rr = mirror(r, kdr[i], x), cc = mirror(c, kdc[i], y);
+            const int at = kb[i] + (cc - ty0 + 1) * DRX + (rr - tx0 + 1);
+            val.v[i] = reg[i < have ? at : 0];
+        }
+        int nxt = snext[pix];
+        while (rowi >= 0) {                        // the pixel's chain: once, unless the list repeats the pixel
+            T *dst = out + (long)rowi * cube_len + (long)b0 * NB + VW * lane;
+            if (have == VW) {
+                store16_unaligned(dst, val.bits);
+            } else {
+#pragma unroll
+                for (int i = 0; i < VW; i++)
+                    if (i < have) dst[i] = val.v[i];
+            }
+            rowi = nxt;
+            if (rowi >= 0) nxt = w.next[rowi];
+        }
+    }
+}
+
 }  // namespace ccnn
+
+// One sample list prepared for repeated gathers (ccnn_gather_plan_create).
+struct ccnn_gather_plan {
+    const int *idx9;
+    long n;
+    int x, y;
+    int kind;        // 0: samples visited in centre-pixel order (sorted list); 1: dense tiles
+    int ntiles;      // dense: non-empty tiles
+    void *ws;
+    size_t ws_bytes;
+};
+
+namespace {
+template <typename T>
+int gather_planned(const ccnn_gather_plan *pl, const T *scene, int z, T *out, hipStream_t st)
+{
+    using namespace ccnn;
+    if (!pl || z <= 0) return CCNN_E_INVALID;
+    if (pl->n == 0) return 0;
+    if (!scene || !out) return CCNN_E_INVALID;
+    if (pl->kind == 0)
+        return gather_impl<T>(scene, pl->idx9, pl->n, pl->x, pl->y, z, out, pl->ws, GatherWs::bytes(pl->n), st, true);
+    DenseWs w(static_cast<char *>(pl->ws) + GatherWs::bytes(pl->n), pl->n, pl->x, pl->y);
+    const int nchunks = (z + DenseCfg<T>::DB - 1) / DenseCfg<T>::DB;
+    launch("gather_dense", gather_dense<T>, dim3((unsigned)pl->ntiles, (unsigned)nchunks), dim3(256), 0, st, scene, pl->x,
+           pl->y, z, (long)pl->x * pl->y, w, out);
+    CCNN_LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace
 
 extern "C" {
 
@@ -259,25 +449,87 @@ int ccnn_gather_f64(const double *scene, const int *idx9, long n, int x, int y, 
     return ccnn::gather_impl<double>(scene, idx9, n, x, y, z, out, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
-int ccnn_gather_plan(const int *idx9, long n, int x, int y, void *workspace, size_t workspace_bytes, void *stream)
+size_t ccnn_gather_plan_workspace_bytes(long n, int x, int y)
 {
-    if (n < 0 || x <= 0 || y <= 0) return CCNN_E_INVALID;
+    if (n <= 0 || x <= 0 || y <= 0) return 0;
+    return ccnn::GatherWs::bytes(n) + ccnn::DenseWs::bytes(n, x, y);
+}
+
+int ccnn_gather_plan_create(const int *idx9, long n, int x, int y, void *workspace, size_t workspace_bytes, void *stream,
+                            ccnn_gather_plan_t **plan)
+{
+    using namespace ccnn;
+    if (!plan || n < 0 || x <= 0 || y <= 0) return CCNN_E_INVALID;
     if ((long)x * y > 0x7fffffffL || n > 0x7fffffffL) return CCNN_E_RANGE;
-    if (n <= ccnn::GS) return 0;   // short lists are gathered without an order
-    if (!idx9 || !workspace) return CCNN_E_INVALID;
-    return ccnn::gather_order(idx9, n, x, y, workspace, workspace_bytes, (hipStream_t)stream);
+    if (n > 0 && (!idx9 || !workspace)) return CCNN_E_INVALID;
+    if (n > 0 && workspace_bytes < ccnn_gather_plan_workspace_bytes(n, x, y)) return CCNN_E_WORKSPACE;
+    ccnn_gather_plan *pl = new (std::nothrow) ccnn_gather_plan{idx9, n, x, y, 0, 0, workspace, workspace_bytes};
+    if (!pl) return (int)hipErrorOutOfMemory;
+    hipStream_t st = (hipStream_t)stream;
+    if (n > GS) {
+        // the dense candidate first: table, tile list and the count of samples that are not plain
+        // neighbourhoods (one synchronisation: the host decides which kernel later calls launch)
+        char *dense_ws = static_cast<char *>(workspace) + GatherWs::bytes(n);
+        DenseWs w(dense_ws, n, x, y);
+        const long nt = (long)((x + DTX - 1) / DTX) * ((y + DTY - 1) / DTY);
+        hipError_t e = hipMemsetAsync(w.head, 0xff, (size_t)x * y * sizeof(int), st);
+        if (e == hipSuccess) e = hipMemsetAsync(w.tile_count, 0, (size_t)nt * sizeof(int), st);
+        if (e == hipSuccess) e = hipMemsetAsync(w.counters, 0, 16 * sizeof(int), st);
+        if (e != hipSuccess) {
+            delete pl;
+            return (int)e;
+        }
+        launch("dense_build", dense_build, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, idx9, n, x, y, w);
+        int counters[2] = {0, 0};
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(counters, w.counters, sizeof(counters), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            delete pl;
+            return (int)e;
+        }
+        // Tiles when every sample is a plain neighbourhood, the tiles they touch are at least three
+        // quarters full and the list is long enough to fill the chip several times over: measured,
+        // a fully labelled 610 x 340 x 103 scene gathers in 317 us by tiles against 384 us by the
+        // ordered list, while on shorter or sparser lists (a 145 x 145 scene fully labelled, the
+        // training lists of the three published scenes) the ordered list is as fast or faster -
+        // both kernels are then bound by the scattered 1 KB writes, not by the reads the tiles save.
+        const char *force = getenv("CCNN_GATHER_PLAN");   // tests: "dense" / "sorted" override the occupancy rule
+        const bool plain = counters[1] == 0 && counters[0] > 0;
+        bool dense = plain && n >= DENSE_MIN_SAMPLES && n * 4 >= 3L * counters[0] * DTX * DTY;
+        if (force && !strcmp(force, "dense")) dense = plain;
+        if (force && !strcmp(force, "sorted")) dense = false;
+        if (dense) {
+            pl->kind = 1;
+            pl->ntiles = counters[0];
+        } else if (int rc = gather_order(idx9, n, x, y, workspace, GatherWs::bytes(n), st)) {
+            delete pl;
+            return rc;
+        }
+    }
+    *plan = pl;
+    return 0;
 }
 
-int ccnn_gather_planned_f32(const float *scene, const int *idx9, long n, int x, int y, int z, float *out,
-                            void *workspace, size_t workspace_bytes, void *stream)
+int ccnn_gather_plan_kind(const ccnn_gather_plan_t *plan)
 {
-    return ccnn::gather_impl<float>(scene, idx9, n, x, y, z, out, workspace, workspace_bytes, (hipStream_t)stream, true);
+    return plan ? plan->kind : CCNN_E_INVALID;
 }
 
-int ccnn_gather_planned_f64(const double *scene, const int *idx9, long n, int x, int y, int z, double *out,
-                            void *workspace, size_t workspace_bytes, void *stream)
+int ccnn_gather_plan_destroy(ccnn_gather_plan_t *plan)
 {
-    return ccnn::gather_impl<double>(scene, idx9, n, x, y, z, out, workspace, workspace_bytes, (hipStream_t)stream, true);
+    delete plan;
+    return 0;
+}
+
+int ccnn_gather_planned_f32(const ccnn_gather_plan_t *plan, const float *scene, int z, float *out, void *stream)
+{
+    return gather_planned<float>(plan, scene, z, out, (hipStream_t)stream);
+}
+
+int ccnn_gather_planned_f64(const ccnn_gather_plan_t *plan, const double *scene, int z, double *out, void *stream)
+{
+    return gather_planned<double>(plan, scene, z, out, (hipStream_t)stream);
 }
 
 int ccnn_get_dims(int z, ccnn_dims_t *dims) { return ccnn::make_dims(z, dims); }

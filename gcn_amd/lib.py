@@ -33,9 +33,12 @@ _SIG = {
     "ccnn_gather_workspace_bytes": (C.c_size_t, [C.c_long]),
     "ccnn_gather_f32": (C.c_int, [_P, _P, C.c_long, C.c_int, C.c_int, C.c_int, _P, _P, C.c_size_t, _P]),
     "ccnn_gather_f64": (C.c_int, [_P, _P, C.c_long, C.c_int, C.c_int, C.c_int, _P, _P, C.c_size_t, _P]),
-    "ccnn_gather_plan": (C.c_int, [_P, C.c_long, C.c_int, C.c_int, _P, C.c_size_t, _P]),
-    "ccnn_gather_planned_f32": (C.c_int, [_P, _P, C.c_long, C.c_int, C.c_int, C.c_int, _P, _P, C.c_size_t, _P]),
-    "ccnn_gather_planned_f64": (C.c_int, [_P, _P, C.c_long, C.c_int, C.c_int, C.c_int, _P, _P, C.c_size_t, _P]),
+    "ccnn_gather_plan_workspace_bytes": (C.c_size_t, [C.c_long, C.c_int, C.c_int]),
+    "ccnn_gather_plan_create": (C.c_int, [_P, C.c_long, C.c_int, C.c_int, _P, C.c_size_t, _P, C.POINTER(_P)]),
+    "ccnn_gather_plan_kind": (C.c_int, [_P]),
+    "ccnn_gather_plan_destroy": (C.c_int, [_P]),
+    "ccnn_gather_planned_f32": (C.c_int, [_P, _P, C.c_int, _P, _P]),
+    "ccnn_gather_planned_f64": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "ccnn_forward_workspace_bytes": (C.c_size_t, [C.c_long, C.c_int, C.c_int]),
     "ccnn_forward_f32": (C.c_int, [_P, _P, C.c_long, C.c_int, _P, _P, _P, C.c_size_t, _P]),
     "ccnn_forward_f64": (C.c_int, [_P, _P, C.c_long, C.c_int, _P, _P, _P, C.c_size_t, _P]),

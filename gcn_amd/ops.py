@@ -80,9 +80,11 @@ def gather(scene, idx9, x, y, z, out=None, workspace=None, sort=True):
 
 
 class GatherPlan:
-    """The order of one sample list, kept for repeated gathers of that list (other scenes, other
-    passes): `GatherPlan(idx9, x, y)` runs the ordering pass once; `plan.gather(scene, z)` only the
-    tile kernel.  Holds its own workspace; idx9 must stay alive and unchanged."""
+    """One sample list prepared for repeated gathers (other scenes, other passes):
+    `GatherPlan(idx9, x, y)` looks at the list once; `plan.gather(scene, z)` then runs only the
+    gather kernel - tiles staged in LDS (`plan.dense`) for densely labelled lists of plain 3x3
+    neighbourhoods, the ordered-list kernel otherwise.  Holds its own workspace; idx9 must stay
+    alive and unchanged."""
 
     def __init__(self, idx9, x, y):
         _req(idx9, torch.int32, "idx9")
@@ -91,10 +93,12 @@ class GatherPlan:
         if idx9.numel() != self.n * 9:
             raise ValueError("idx9 must hold 9 indices per sample")
         lib = _l.load()
-        nbytes = lib.ccnn_gather_workspace_bytes(self.n)
+        nbytes = lib.ccnn_gather_plan_workspace_bytes(self.n, x, y)
         self.ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=idx9.device)
-        _l.check(lib.ccnn_gather_plan(_ptr(idx9), self.n, x, y, _ptr(self.ws), self.ws.numel(), _stream()),
-                 "ccnn_gather_plan")
+        self._h = C.c_void_p()
+        _l.check(lib.ccnn_gather_plan_create(_ptr(idx9), self.n, x, y, _ptr(self.ws), self.ws.numel(), _stream(),
+                                             C.byref(self._h)), "ccnn_gather_plan_create")
+        self.dense = lib.ccnn_gather_plan_kind(self._h) == 1
 
     def gather(self, scene, z, out=None):
         sfx, _ = _sfx(scene.dtype)
@@ -103,9 +107,13 @@ class GatherPlan:
             out = torch.empty((self.n, 9 * z), dtype=scene.dtype, device=scene.device)
         _req(out, scene.dtype, "out", self.n * 9 * z)
         fn = getattr(_l.load(), f"ccnn_gather_planned_{sfx}")
-        _l.check(fn(_ptr(scene), _ptr(self.idx9), self.n, self.x, self.y, z, _ptr(out), _ptr(self.ws), self.ws.numel(),
-                    _stream()), f"ccnn_gather_planned_{sfx}")
+        _l.check(fn(self._h, _ptr(scene), z, _ptr(out), _stream()), f"ccnn_gather_planned_{sfx}")
         return out
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _l is not None:      # module globals are gone at interpreter exit
+            _l.load().ccnn_gather_plan_destroy(self._h)
+            self._h = None
 
 
 def forward(params, cubes, z, want_probs=True, want_argmax=True, workspace=None):

@@ -84,17 +84,26 @@ int ccnn_gather_f64(const double *scene, const int *idx9, long n, int x, int y, 
                     double *out, void *workspace, size_t workspace_bytes, void *stream);
 
 /* The same gather for a sample list that is gathered more than once (several scenes with one
- * label mask, repeated passes): ccnn_gather_plan does the ordering pass of ccnn_gather_* once and
- * leaves the order in the workspace; ccnn_gather_planned_* then only runs the tile kernel.  The
- * workspace (ccnn_gather_workspace_bytes(n) bytes) belongs to that idx9 list until it is planned
- * again; the preprocessing / processing launches replaced are those of ccnn_gather_*.  Results
- * are identical to ccnn_gather_*. */
-int ccnn_gather_plan(const int *idx9, long n, int x, int y, void *workspace, size_t workspace_bytes,
-                     void *stream);
-int ccnn_gather_planned_f32(const float *scene, const int *idx9, long n, int x, int y, int z,
-                            float *out, void *workspace, size_t workspace_bytes, void *stream);
-int ccnn_gather_planned_f64(const double *scene, const int *idx9, long n, int x, int y, int z,
-                            double *out, void *workspace, size_t workspace_bytes, void *stream);
+ * label mask, repeated passes).  ccnn_gather_plan_create looks at the list once (it synchronises
+ * the stream) and keeps, in the caller's workspace, what later calls need: for lists of at least
+ * 65536 plain 3x3 neighbourhoods (as ccnn_host_build_index makes them) that fill three quarters
+ * of the 32 x 8 pixel tiles they touch, a pixel -> sample table and the list of those tiles - the
+ * gather then stages each tile with its halo once in LDS and needs no sort (fully or densely
+ * labelled scenes); for every other list, the centre-pixel order ccnn_gather_* would compute on
+ * each call.  ccnn_gather_planned_* gathers the planned list from a scene; results are identical
+ * to ccnn_gather_*.  idx9 and the workspace (ccnn_gather_plan_workspace_bytes(n, x, y) bytes)
+ * must stay alive and unchanged while the plan is used.  ccnn_gather_plan_kind: 1 = tiles,
+ * 0 = ordered list.  The launches replaced are those of ccnn_gather_*. */
+typedef struct ccnn_gather_plan ccnn_gather_plan_t;
+size_t ccnn_gather_plan_workspace_bytes(long n, int x, int y);
+int ccnn_gather_plan_create(const int *idx9, long n, int x, int y, void *workspace,
+                            size_t workspace_bytes, void *stream, ccnn_gather_plan_t **plan);
+int ccnn_gather_plan_kind(const ccnn_gather_plan_t *plan);
+int ccnn_gather_plan_destroy(ccnn_gather_plan_t *plan);
+int ccnn_gather_planned_f32(const ccnn_gather_plan_t *plan, const float *scene, int z, float *out,
+                            void *stream);
+int ccnn_gather_planned_f64(const ccnn_gather_plan_t *plan, const double *scene, int z, double *out,
+                            void *stream);
 
 /* Forward pass over n cubes: the test loop's convolution / maxpooling /
  * fully_connect / output_and_dvalue(false) launches plus the host count_err

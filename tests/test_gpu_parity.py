@@ -73,9 +73,13 @@ def test_gather_ragged_and_empty(dtype):
         assert out.tobytes() == orc.gather(scene, idx.reshape(-1, 9), x, y, z).tobytes()
 
 
+@pytest.mark.parametrize("force", [None, "dense", "sorted"])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_gather_planned_equals_gather(dtype):
-    """One ordering pass, several gathers (two scenes with the same label mask, different band counts)."""
+def test_gather_planned_equals_gather(dtype, force, monkeypatch):
+    """One look at the list, several gathers (two scenes with the same label mask, different band
+    counts), with the plan's own choice of kernel and with either kernel forced."""
+    if force:
+        monkeypatch.setenv("CCNN_GATHER_PLAN", force)
     x, y = 37, 29
     _, labels = synth.small_scene(x, y, 21, 5, dtype)
     di = prep.scan_labels(labels, x, y)
@@ -84,10 +88,63 @@ def test_gather_planned_equals_gather(dtype):
     for idx in (tr9, tr9[:16], tr9[:17], tr9[:0]):
         idx_d = dev(np.ascontiguousarray(idx.reshape(-1, 9)))
         plan = ops.GatherPlan(idx_d, x, y)
+        if force and len(idx) > 16:
+            assert plan.dense == (force == "dense")
         for z, seed in ((103, 1), (40, 2), (103, 3)):
             scene = np.random.default_rng(seed).random(x * y * z).astype(dtype)
             out = plan.gather(dev(scene), z).cpu().numpy()
             assert out.tobytes() == orc.gather(scene, idx.reshape(-1, 9), x, y, z).tobytes(), (len(idx), z)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_gather_dense_fully_labelled_scene(dtype, monkeypatch):
+    """Every pixel of a 64 x 50 x 224 scene labelled: the plan picks the tile kernel; mirrored
+    borders, partial tiles on both axes, a list that repeats pixels, and a list with one sample
+    that is not a plain neighbourhood (the plan must fall back to the ordered list)."""
+    x, y, z = 64, 50, 224
+    monkeypatch.setenv("CCNN_GATHER_PLAN", "dense")     # 3200 samples: below the length the plan asks for by itself
+    rng = np.random.default_rng(77)
+    labels = rng.integers(1, 14, x * y).astype(np.int32)
+    scene = rng.random(x * y * z).astype(dtype)
+    di = prep.scan_labels(labels, x, y)
+    tr9, te9, _, _ = prep.build_index(labels, di, x, y)
+    every = np.concatenate([tr9.reshape(-1, 9), te9.reshape(-1, 9)])
+    assert len(every) == x * y
+    every = every[rng.permutation(len(every))]
+    repeated = np.concatenate([every, every[:1500], every[:700]])
+    repeated = repeated[rng.permutation(len(repeated))]
+    odd = every.copy()
+    odd[1234, 0], odd[1234, 8] = odd[1234, 8], odd[1234, 0]
+    sc = dev(scene)
+    for idx, dense in ((every, True), (repeated, True), (odd, False)):
+        idx = np.ascontiguousarray(idx)
+        plan = ops.GatherPlan(dev(idx), x, y)
+        assert plan.dense == dense
+        out = plan.gather(sc, z).cpu().numpy()
+        assert out.tobytes() == orc.gather(scene, idx, x, y, z).tobytes()
+        # a second scene with fewer bands through the same plan
+        out = plan.gather(sc[: x * y * 33].contiguous(), 33).cpu().numpy()
+        assert out.tobytes() == orc.gather(scene[: x * y * 33], idx, x, y, 33).tobytes()
+
+
+def test_gather_plan_picks_tiles_for_a_large_fully_labelled_scene():
+    """610 x 340 pixels all labelled, 20 bands: the plan chooses the tile kernel by itself and the
+    result equals plain indexing, checked on the device."""
+    x, y, z = 610, 340, 20
+    rng = np.random.default_rng(5)
+    labels = rng.integers(1, 14, x * y).astype(np.int32)
+    di = prep.scan_labels(labels, x, y)
+    tr9, te9, _, _ = prep.build_index(labels, di, x, y)
+    idx = np.concatenate([tr9.reshape(-1, 9), te9.reshape(-1, 9)])
+    idx = np.ascontiguousarray(idx[rng.permutation(len(idx))])
+    sc = torch.rand(x * y * z, dtype=torch.float32, device="cuda")
+    idx_d = dev(idx)
+    plan = ops.GatherPlan(idx_d, x, y)
+    assert plan.dense
+    out = plan.gather(sc, z)
+    ref = sc.view(z, x * y)[:, idx_d.long()].permute(1, 0, 2).reshape(len(idx), 9 * z)
+    assert torch.equal(out, ref)
+    assert torch.equal(out, ops.gather(sc, idx_d, x, y, z))
 
 
 def test_gather_full_size_property():
