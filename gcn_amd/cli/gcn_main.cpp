@@ -15,6 +15,8 @@
 // Options (all before the positional arguments):
 //   --variant=V  --seed=N (default: time, like the reference)  --epochs=N (300)
 //   --batch=N (100)  --model=PATH (load weights instead of initialising)
+//   --classes=N (2..16; default 13 like the reference's NEU_NUM2, or the largest label when the
+//                label map holds 14..16 classes - the reference needs a rebuild for those)
 //   --exchange=rccl|oneshot (multi-GPU form: gradient exchange, default rccl)
 //   --tail=keep|drop (single GPU MBGD: train the last T % B samples as a short batch; default drop)
 //   --preprocess (write traindata.mat / testdata.mat like pre-treatment/preprocess048 and stop)
@@ -66,7 +68,7 @@ struct Options {
     std::string variant = "mbgd_fp32", model;
     bool variant_given = false;
     long seed = -1;
-    int epochs = 300, batch = 100;
+    int epochs = 300, batch = 100, classes = 0;   // classes 0: 13, or the largest label if that is 14..16
     bool infer = false, preprocess = false, keep_tail = false;
     std::string exchange = "rccl";   // multi-GPU gradient exchange: rccl | oneshot
     std::vector<std::string> pos;
@@ -150,8 +152,8 @@ void save_model(const Variant &v, const ccnn_dims_t &d, const std::vector<double
         {v.names[1], (size_t)CCNN_FILTERS, 1, params.data() + d.off_b0},
         {v.names[2], (size_t)CCNN_HIDDEN, (size_t)d.pout, params.data() + d.off_w1},
         {v.names[3], (size_t)CCNN_HIDDEN, 1, params.data() + d.off_b1},
-        {v.names[4], (size_t)CCNN_CLASSES, (size_t)CCNN_HIDDEN, params.data() + d.off_w2},
-        {v.names[5], (size_t)CCNN_CLASSES, 1, params.data() + d.off_b2},
+        {v.names[4], (size_t)d.n_classes, (size_t)CCNN_HIDDEN, params.data() + d.off_w2},
+        {v.names[5], (size_t)d.n_classes, 1, params.data() + d.off_b2},
         {"loss", logloss.size(), 1, logloss.data()},
     };
     std::string err;
@@ -163,7 +165,7 @@ struct Samples {
     std::vector<int> train_idx9, test_idx9, onehot, test_labels;
 };
 
-Samples build_samples(const std::vector<double> &labels, int x, int y, unsigned seed, bool shuffle = true)
+Samples build_samples(const std::vector<double> &labels, int x, int y, int classes, unsigned seed, bool shuffle = true)
 {
     Samples s;
     std::vector<int> data_index((size_t)x * y);
@@ -176,11 +178,11 @@ Samples build_samples(const std::vector<double> &labels, int x, int y, unsigned 
     CK(ccnn_host_split_sizes(n, &s.n_train, &s.n_test));
     s.train_idx9.resize((size_t)s.n_train * 9);
     s.test_idx9.resize((size_t)s.n_test * 9);
-    s.onehot.resize((size_t)s.n_train * CCNN_CLASSES);
+    s.onehot.resize((size_t)s.n_train * classes);
     s.test_labels.resize(s.n_test);
-    CK(ccnn_host_build_index(labels.data(), data_index.data(), n, x, y, s.train_idx9.data(), s.test_idx9.data(),
-                             s.onehot.data(), s.test_labels.data()));
-    if (shuffle) CK(ccnn_host_shuffle(s.train_idx9.data(), s.onehot.data(), s.n_train, seed));
+    CK(ccnn_host_build_index_classes(labels.data(), data_index.data(), n, x, y, classes, s.train_idx9.data(),
+                                     s.test_idx9.data(), s.onehot.data(), s.test_labels.data()));
+    if (shuffle) CK(ccnn_host_shuffle_classes(s.train_idx9.data(), s.onehot.data(), s.n_train, classes, seed));
     return s;
 }
 
@@ -317,15 +319,16 @@ void stream_scene(matio::Stream &ds, const std::vector<int> &ids, const std::vec
 
 template <typename T>
 double run(const Options &opt, const Variant &v, matio::Stream &ds, const std::vector<double> &labels, int x, int y, int z,
-           const std::vector<int> &devices)
+           int classes, const std::vector<int> &devices)
 {
+    const int zg = classes == CCNN_CLASSES ? z : CCNN_GEOMETRY(z, classes);   // what the network entry points take as z
     const int nd = (int)devices.size();
     const bool multi = opt.pos.size() == 3;
     Clock::time_point t0 = Clock::now();
     ccnn_dims_t d;
-    CK(ccnn_get_dims(z, &d));
+    CK(ccnn_get_dims(zg, &d));
     const unsigned seed = opt.seed >= 0 ? (unsigned)opt.seed : (unsigned)time(NULL);
-    Samples s = build_samples(labels, x, y, seed);
+    Samples s = build_samples(labels, x, y, classes, seed);
 
     // weights: libc rand() continues from the shuffle, in the reference's draw order
     const int B = opt.batch;
@@ -334,10 +337,10 @@ double run(const Options &opt, const Variant &v, matio::Stream &ds, const std::v
         if (!load_model(opt.model, d, params_h)) exit(EXIT_FAILURE);
     } else if (v.f32) {
         std::vector<float> p(d.nparams);
-        CK(ccnn_host_init_params_f32(p.data(), z));
+        CK(ccnn_host_init_params_f32(p.data(), zg));
         std::copy(p.begin(), p.end(), params_h.begin());
     } else {
-        CK(ccnn_host_init_params_f64(params_h.data(), z, v.sgd ? d.pout : (long)d.pout * B));
+        CK(ccnn_host_init_params_f64(params_h.data(), zg, v.sgd ? d.pout : (long)d.pout * B));
     }
     std::vector<T> params_t(params_h.begin(), params_h.end());
 
@@ -402,15 +405,15 @@ double run(const Options &opt, const Variant &v, matio::Stream &ds, const std::v
     for (int k = 0; k < nd; k++) {
         Device<T> &D = dev[k];
         CK(hipSetDevice(D.id));
-        std::vector<int> oh(s.onehot.begin() + (size_t)k * slice * CCNN_CLASSES,
-                            s.onehot.begin() + (size_t)(k + 1) * slice * CCNN_CLASSES);
+        std::vector<int> oh(s.onehot.begin() + (size_t)k * slice * classes,
+                            s.onehot.begin() + (size_t)(k + 1) * slice * classes);
         D.onehot = to_device(oh);
         D.params = to_device(params_t);
         D.grad = dmalloc<T>(d.nparams);
         D.loss = dmalloc<double>(std::max<long>(batch_num + 1, 1) * std::max(sub_b, 1));
-        D.ws_bytes = v.sgd ? ccnn_sgd_workspace_bytes(z)
-                           : std::max(ccnn_mbgd_workspace_bytes(std::max(sub_b, 1), z, (int)sizeof(T)),
-                                      tail ? ccnn_mbgd_workspace_bytes(tail, z, (int)sizeof(T)) : (size_t)0);
+        D.ws_bytes = v.sgd ? ccnn_sgd_workspace_bytes(zg)
+                           : std::max(ccnn_mbgd_workspace_bytes(std::max(sub_b, 1), zg, (int)sizeof(T)),
+                                      tail ? ccnn_mbgd_workspace_bytes(tail, zg, (int)sizeof(T)) : (size_t)0);
         CK(hipMalloc(&D.ws, D.ws_bytes ? D.ws_bytes : 1));
     }
     // Multi-GPU gradient exchange: RCCL all-reduce + update, or (--exchange=oneshot) the library's
@@ -467,7 +470,7 @@ double run(const Options &opt, const Variant &v, matio::Stream &ds, const std::v
             double single_rate = 0;
             if (v.sgd) {
                 Device<T> &D = dev[0];
-                CK(ccnn_sgd_f64((double *)D.params, (const double *)D.cubes, D.onehot, 0, s.n_train, z, lr, D.loss,
+                CK(ccnn_sgd_f64((double *)D.params, (const double *)D.cubes, D.onehot, 0, s.n_train, zg, lr, D.loss,
                                 D.ws, D.ws_bytes, D.st));
                 double l = 0;
                 CK(hipMemcpyAsync(&l, D.loss, sizeof(double), hipMemcpyDeviceToHost, D.st));
@@ -486,15 +489,15 @@ double run(const Options &opt, const Variant &v, matio::Stream &ds, const std::v
                         if (nd > 1) CK(hipSetDevice(D.id));
                         double *lv = D.loss + i0 * sub_b;
                         if (!exchange) {
-                            CK(Api<T>::step(D.params, D.cubes, D.onehot, i0 * sub_b, sub_b, z, lr, lv, D.ws, D.ws_bytes, D.st));
+                            CK(Api<T>::step(D.params, D.cubes, D.onehot, i0 * sub_b, sub_b, zg, lr, lv, D.ws, D.ws_bytes, D.st));
                         } else if (oneshot) {
                             // gradient, exchange with the other devices and update in two launches; the
                             // launches are asynchronous, so device k's kernel waits for its peers' while
                             // this loop goes on to start them
-                            CK(Api<T>::step_dp(xch[k], D.params, D.cubes, D.onehot, i0 * sub_b, sub_b, z, lr, B, lv, D.ws,
+                            CK(Api<T>::step_dp(xch[k], D.params, D.cubes, D.onehot, i0 * sub_b, sub_b, zg, lr, B, lv, D.ws,
                                                D.ws_bytes, D.st));
                         } else {
-                            CK(Api<T>::grad(D.params, D.cubes, D.onehot, i0 * sub_b, sub_b, z, D.grad, lv, D.ws, D.ws_bytes,
+                            CK(Api<T>::grad(D.params, D.cubes, D.onehot, i0 * sub_b, sub_b, zg, D.grad, lv, D.ws, D.ws_bytes,
                                             D.st));
                         }
                     }
@@ -513,14 +516,14 @@ double run(const Options &opt, const Variant &v, matio::Stream &ds, const std::v
                         NCK(ncclGroupEnd());
                         for (int k = 0; k < nd; k++) {
                             CK(hipSetDevice(dev[k].id));
-                            CK(Api<T>::update(dev[k].params, dev[k].grad, lr, z, B, d.nparams, dev[k].st));
+                            CK(Api<T>::update(dev[k].params, dev[k].grad, lr, zg, B, d.nparams, dev[k].st));
                         }
                     }
                 }
                 if (tail) {
                     Device<T> &D = dev[0];
                     double *lv = D.loss + batch_num * sub_b;
-                    CK(Api<T>::step(D.params, D.cubes, D.onehot, batch_num * sub_b, tail, z, lr, lv, D.ws, D.ws_bytes, D.st));
+                    CK(Api<T>::step(D.params, D.cubes, D.onehot, batch_num * sub_b, tail, zg, lr, lv, D.ws, D.ws_bytes, D.st));
                 }
                 // one D2H per device per epoch; host adds the per-sample losses in order
                 float loss32 = 0;
@@ -584,10 +587,10 @@ double run(const Options &opt, const Variant &v, matio::Stream &ds, const std::v
     }
     CK(hipSetDevice(dev[0].id));
     int *argmax_d = dmalloc<int>(s.n_test), *count_d = dmalloc<int>(1), *tl_d = to_device(s.test_labels);
-    const size_t fws_bytes = ccnn_forward_workspace_bytes(s.n_test, z, (int)sizeof(T));
+    const size_t fws_bytes = ccnn_forward_workspace_bytes(s.n_test, zg, (int)sizeof(T));
     void *fws = nullptr;
     CK(hipMalloc(&fws, fws_bytes ? fws_bytes : 1));
-    CK(Api<T>::forward(dev[0].params, test_d, s.n_test, z, argmax_d, fws, fws_bytes, dev[0].st));
+    CK(Api<T>::forward(dev[0].params, test_d, s.n_test, zg, argmax_d, fws, fws_bytes, dev[0].st));
     CK(ccnn_count_correct(argmax_d, tl_d, s.n_test, count_d, dev[0].st));
     int right = 0;
     CK(hipMemcpyAsync(&right, count_d, sizeof(int), hipMemcpyDeviceToHost, dev[0].st));
@@ -611,12 +614,12 @@ double run(const Options &opt, const Variant &v, matio::Stream &ds, const std::v
 // (:66-262): cubes of all labelled pixels in scan order (no shuffle), fp64, written as
 // testdata.mat {data (9z x test_size), labels (test_size x 1)} and
 // traindata.mat {data (9z x train_size), labels (13 x train_size, one-hot)}.
-int preprocess_dump(matio::Stream &ds, const std::vector<double> &labels, int x, int y, int z, int device)
+int preprocess_dump(matio::Stream &ds, const std::vector<double> &labels, int x, int y, int z, int classes, int device)
 {
     Clock::time_point t0 = Clock::now();
     ccnn_dims_t d;
     CK(ccnn_get_dims(z, &d));
-    Samples s = build_samples(labels, x, y, 0, false);
+    Samples s = build_samples(labels, x, y, classes, 0, false);
     fprintf(stdout, "train_size:%d  test_size:%d\n", s.n_train, s.n_test);
     fprintf(stdout, "Index computing completed!\n");
     CK(hipSetDevice(device));
@@ -648,7 +651,7 @@ int preprocess_dump(matio::Stream &ds, const std::vector<double> &labels, int x,
     if (!matio::write("testdata.mat", {{"data", (size_t)d.cube, (size_t)s.n_test, test.data()},
                                        {"labels", (size_t)s.n_test, 1, tl.data()}}, err) ||
         !matio::write("traindata.mat", {{"data", (size_t)d.cube, (size_t)s.n_train, train.data()},
-                                        {"labels", (size_t)CCNN_CLASSES, (size_t)s.n_train, onehot.data()}}, err)) {
+                                        {"labels", (size_t)classes, (size_t)s.n_train, onehot.data()}}, err)) {
         fprintf(stderr, "%s\n", err.c_str());
         return 1;
     }
@@ -749,6 +752,7 @@ int main(int argc, char *argv[])
         else if (a.rfind("--seed=", 0) == 0) opt.seed = atol(a.c_str() + 7);
         else if (a.rfind("--epochs=", 0) == 0) opt.epochs = atoi(a.c_str() + 9);
         else if (a.rfind("--batch=", 0) == 0) opt.batch = atoi(a.c_str() + 8);
+        else if (a.rfind("--classes=", 0) == 0) opt.classes = atoi(a.c_str() + 10);
         else if (a.rfind("--exchange=", 0) == 0) opt.exchange = a.substr(11);
         else if (a.rfind("--model=", 0) == 0) opt.model = a.substr(8);
         else if (a == "--infer") opt.infer = true;
@@ -853,9 +857,21 @@ int main(int argc, char *argv[])
     }
     lab.close();
 
-    if (opt.preprocess) return preprocess_dump(ds, labels, x, y, z, devices[0]);
-    const double correct = v->f32 ? run<float>(opt, *v, ds, labels, x, y, z, devices)
-                                  : run<double>(opt, *v, ds, labels, x, y, z, devices);
+    // class count: the reference's 13 unless told otherwise or the label map needs more
+    int classes = opt.classes;
+    if (classes == 0) {
+        double top = 0;
+        for (double l : labels) top = std::max(top, l);
+        classes = top > CCNN_CLASSES && top <= CCNN_MAX_CLASSES ? (int)top : CCNN_CLASSES;
+        if (classes != CCNN_CLASSES) fprintf(stderr, "labels run up to %d: training a %d-class output layer\n", classes, classes);
+    }
+    if (classes < CCNN_MIN_CLASSES || classes > CCNN_MAX_CLASSES) {
+        fprintf(stderr, "--classes must be %d..%d\n", CCNN_MIN_CLASSES, CCNN_MAX_CLASSES);
+        return 1;
+    }
+    if (opt.preprocess) return preprocess_dump(ds, labels, x, y, z, classes, devices[0]);
+    const double correct = v->f32 ? run<float>(opt, *v, ds, labels, x, y, z, classes, devices)
+                                  : run<double>(opt, *v, ds, labels, x, y, z, classes, devices);
     fprintf(stdout, "Accuracy: %.3f%% \n", correct * 100);
     return 0;
 }

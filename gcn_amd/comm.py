@@ -105,8 +105,8 @@ class NodeComm:
         p0 = torch.from_numpy(((rng.random(d.nparams) - 0.5) / 10).astype(npdt)).to(self.device)
         rng = np.random.default_rng(78 + self.rank)          # different samples
         cubes = torch.from_numpy(rng.random((B, d.cube)).astype(npdt)).to(self.device)
-        oh = np.zeros((B, 13), dtype=np.int32)
-        oh[np.arange(B), rng.integers(0, 13, B)] = 1
+        oh = np.zeros((B, d.n_classes), dtype=np.int32)
+        oh[np.arange(B), rng.integers(0, d.n_classes, B)] = 1
         oh = torch.from_numpy(oh).to(self.device)
         lr = 0.04
         p_dp, p_ref = p0.clone(), p0.clone()

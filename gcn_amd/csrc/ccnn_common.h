@@ -12,17 +12,23 @@ namespace ccnn {
 constexpr int F = CCNN_FILTERS;       // 20 filters
 constexpr int K = CCNN_FILTER_SIZE;   // 171 taps = 19 bands x 9 neighbours
 constexpr int H = CCNN_HIDDEN;        // 100
-constexpr int O = CCNN_CLASSES;       // 13
+constexpr int OMAX = CCNN_MAX_CLASSES;   // 16: the output layer fits one 16-wide tile / 16 lanes whatever the class count
 constexpr int NB = CCNN_PER_LAYER;    // 9 values per band
 constexpr int WSTEP = NB * CCNN_STRIDE;  // 18: cube offset between conv windows
 constexpr int PCHUNK = 64;            // pooled features per FC1 K-chunk
 
 struct Dims : ccnn_dims_t {};
 
-inline int make_dims(int z, ccnn_dims_t *d)
+// `geometry` is a band count, or CCNN_GEOMETRY(bands, classes) for a class count other than 13.
+inline int make_dims(int geometry, ccnn_dims_t *d)
 {
-    if (!d || z < CCNN_MIN_BANDS || z > CCNN_MAX_BANDS) return CCNN_E_INVALID;
+    if (!d || geometry < 0) return CCNN_E_INVALID;
+    const int z = geometry & 0xffff;
+    const int classes = (geometry >> 16) ? (geometry >> 16) : CCNN_CLASSES;
+    if (z < CCNN_MIN_BANDS || z > CCNN_MAX_BANDS) return CCNN_E_INVALID;
+    if (classes < CCNN_MIN_CLASSES || classes > CCNN_MAX_CLASSES) return CCNN_E_INVALID;
     d->z = z;
+    d->n_classes = classes;
     d->cube = NB * z;
     d->re = (z - CCNN_COV_LEN - 1) / CCNN_STRIDE + 1;   // gcn_mbgd_fp64.cu:199
     d->mre = (d->re - 1) / CCNN_POOL_LEN + 1;
@@ -33,8 +39,8 @@ inline int make_dims(int z, ccnn_dims_t *d)
     d->off_w1 = d->off_b0 + F;
     d->off_b1 = d->off_w1 + d->pout * H;
     d->off_w2 = d->off_b1 + H;
-    d->off_b2 = d->off_w2 + H * O;
-    d->nparams = d->off_b2 + O;
+    d->off_b2 = d->off_w2 + H * classes;
+    d->nparams = d->off_b2 + classes;
     return 0;
 }
 

@@ -91,21 +91,49 @@ struct Vec16 {
     static constexpr int W = 16 / sizeof(T);
     typedef T type __attribute__((ext_vector_type(16 / sizeof(T))));
 };
-// The reference's ceil-halving tree over 13 values (13 -> 7 -> 4 -> 2 -> 1), in
-// registers: t[i] += t[i+7] (i<6); t[i] += t[i+4] (i<3); t[i] += t[i+2] (i<2); t[0] += t[1].
-template <typename T>
-__device__ __forceinline__ T tree13(const T *v)
+// The reference's ceil-halving tree over n values (gcn_mbgd_fp64.cu:337-346: offset = ceil(n/2);
+// t[i] += t[i + offset] while i + offset < n; then n = offset ..; 13 -> 7 -> 4 -> 2 -> 1), in
+// registers.  The pairing depends on n, so each class count has its own unrolled tree and the
+// run-time count picks one (a wave-uniform branch).
+template <typename T, int N>
+__device__ __forceinline__ T tree_fixed(const T *v)
 {
-    T t[O];
+    T t[N];
 #pragma unroll
-    for (int i = 0; i < O; i++) t[i] = v[i];
+    for (int i = 0; i < N; i++) t[i] = v[i];
+    int len = N;
 #pragma unroll
-    for (int i = 0; i < 6; i++) t[i] = t[i] + t[i + 7];
+    for (int lvl = 0; lvl < 4; lvl++) {
+        const int off = (len - 1) / 2 + 1;
+        if (len >= 2) {
 #pragma unroll
-    for (int i = 0; i < 3; i++) t[i] = t[i] + t[i + 4];
-    t[0] = t[0] + t[2];
-    t[1] = t[1] + t[3];
-    return t[0] + t[1];
+            for (int i = 0; i < N; i++)
+                if (i + off < len) t[i] = t[i] + t[i + off];
+        }
+        len = off;
+    }
+    return t[0];
+}
+template <typename T>
+__device__ __forceinline__ T tree_n(const T *v, int n)
+{
+    switch (n) {
+    case 2: return tree_fixed<T, 2>(v);
+    case 3: return tree_fixed<T, 3>(v);
+    case 4: return tree_fixed<T, 4>(v);
+    case 5: return tree_fixed<T, 5>(v);
+    case 6: return tree_fixed<T, 6>(v);
+    case 7: return tree_fixed<T, 7>(v);
+    case 8: return tree_fixed<T, 8>(v);
+    case 9: return tree_fixed<T, 9>(v);
+    case 10: return tree_fixed<T, 10>(v);
+    case 11: return tree_fixed<T, 11>(v);
+    case 12: return tree_fixed<T, 12>(v);
+    case 14: return tree_fixed<T, 14>(v);
+    case 15: return tree_fixed<T, 15>(v);
+    case 16: return tree_fixed<T, 16>(v);
+    default: return tree_fixed<T, 13>(v);
+    }
 }
 
 // Per-sample loss as the two MBGD references define it, split so that the 13
@@ -117,11 +145,11 @@ __device__ __forceinline__ void loss_terms(double p, int lab, double *ta, double
     *ta = lab * log(p);
     *tb = (1 - lab) * log(1 - p);
 }
-__device__ __forceinline__ double loss_sum(const double *ta, const double *tb, const int *lab)
+__device__ __forceinline__ double loss_sum(const double *ta, const double *tb, const int *lab, int no)
 {
     double tmp = 0.0;
-    for (int i = 0; i < O; i++) tmp = tmp + ta[i] + tb[i];
-    return -tmp / O;
+    for (int i = 0; i < no; i++) tmp = tmp + ta[i] + tb[i];
+    return -tmp / no;
 }
 // fp32: class-balanced logistic expression on the probabilities, float inner
 // arithmetic, double accumulators                   (gcn_mbgd_fp32.cu:578-604)
@@ -131,11 +159,11 @@ __device__ __forceinline__ void loss_terms(float o, int lab, float *ta, float *t
     *ta = o * (lab - ge) - logf(1 + expf(o - 2 * o * ge));
     *tb = 0;
 }
-__device__ __forceinline__ double loss_sum(const float *ta, const float *tb, const int *lab)
+__device__ __forceinline__ double loss_sum(const float *ta, const float *tb, const int *lab, int no)
 {
     int count_pos = 0, count_neg = 0;
     double pos = 0, neg = 0;
-    for (int i = 0; i < O; i++) {
+    for (int i = 0; i < no; i++) {
         if (lab[i] == 1) {
             count_pos++;
             pos -= ta[i];
@@ -144,7 +172,7 @@ __device__ __forceinline__ double loss_sum(const float *ta, const float *tb, con
             neg -= ta[i];
         }
     }
-    return (pos * count_neg / O) * 1 + (neg * count_pos / O);
+    return (pos * count_neg / no) * 1 + (neg * count_pos / no);
 }
 
 // Sum of 16 per-lane values over the QL (32 or 64) lanes of a group with ~1 shuffle

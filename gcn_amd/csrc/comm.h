@@ -166,6 +166,7 @@ struct ccnn_comm {
     size_t total_bytes;   // bytes of the exchange buffer
     unsigned long long identity;   // PCI identity of this rank's GPU
     bool shared_device;   // some peer rank runs on this rank's own GPU (known after connect)
+    bool any_shared;      // some two ranks of the group share a GPU: the same answer on every rank
     bool opened[ccnn::COMM_MAX_RANKS];
     unsigned step;
     unsigned nonce;   // drawn at creation; the ranks' nonces together seed the sequence numbers

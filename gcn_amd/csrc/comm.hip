@@ -186,7 +186,7 @@ int ccnn_comm_create(int world, int rank, long max_elems, int elem_size, ccnn_co
     }
     hipError_t e = hipGetDevice(&cm->device);
     void *buf = nullptr;
-    cm->shared_device = false;
+    cm->shared_device = cm->any_shared = false;
     // uncached: peers write it over xGMI behind the local L2's back
     if (e == hipSuccess) e = hipExtMallocWithFlags(&buf, cm->total_bytes, hipDeviceMallocUncached);
     if (e == hipSuccess) e = hipMemset(buf, 0, cm->total_bytes);
@@ -230,6 +230,7 @@ int ccnn_comm_connect(ccnn_comm_t *cm, const void *handles)
     // combine the nonces into the first sequence number (the same on every rank), and note
     // whether a peer sits on this rank's own GPU
     unsigned seed = 0;
+    unsigned long long ids[COMM_MAX_RANKS];
     for (int r = 0; r < cm->dev.world; r++) {
         unsigned v = 0;
         unsigned long long id = 0;
@@ -238,6 +239,9 @@ int ccnn_comm_connect(ccnn_comm_t *cm, const void *handles)
         if (e != hipSuccess) return (int)e;
         seed = seed * 2654435761u + v;
         if (r != cm->dev.rank && id == cm->identity) cm->shared_device = true;
+        ids[r] = id;
+        for (int q = 0; q < r; q++)
+            if (ids[q] == id) cm->any_shared = true;
     }
     cm->step = seed | 1u;
     return 0;
@@ -259,6 +263,9 @@ int ccnn_comm_connect_local(ccnn_comm_t *cm, ccnn_comm_t *const *peers)
         cm->dev.peer[r] = peers[r]->dev.peer[r];
         if (peers[r]->identity == cm->identity) cm->shared_device = true;
     }
+    for (int r = 0; r < cm->dev.world; r++)
+        for (int q = 0; q < r; q++)
+            if ((r == cm->dev.rank ? cm : peers[r])->identity == (q == cm->dev.rank ? cm : peers[q])->identity) cm->any_shared = true;
     unsigned seed = 0;
     for (int r = 0; r < cm->dev.world; r++) seed = seed * 2654435761u + (r == cm->dev.rank ? cm->nonce : peers[r]->nonce);
     cm->step = seed | 1u;

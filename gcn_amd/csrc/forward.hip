@@ -272,8 +272,8 @@ template <typename T, int MS>
 struct FcHeadLds {
     static constexpr int wl = 0;                                   // [64][LDW1]   W1 chunk; later z1s[32][LDZ]
     static constexpr int pt = wl + PCHUNK * LDW1;                  // [32][LDP]    pool chunk
-    static constexpr int w2 = pt + ((MS * LDP + 3) & ~3);       // [1300]       W2
-    static constexpr int b1 = w2 + ((H * O + 3) & ~3);             // [100]
+    static constexpr int w2 = pt + ((MS * LDP + 3) & ~3);       // [100 x classes] W2
+    static constexpr int b1 = w2 + H * OMAX;                        // [100]
     static constexpr int b2 = b1 + H;                              // [16]
     static constexpr int es = b2 + 16;                             // [32][16]
     static constexpr int ps = es + MS * 16;                     // [32][16]
@@ -297,24 +297,26 @@ extern "C" int ccnn_debug_fc_wg(unsigned long long *out)
 
 // TRAIN (the minibatch step's forward half): the epilogue goes on to what output_and_dvalue and the
 // first bp_fully_connect produce per sample (gcn_mbgd_fp64.cu:307-354, 401-436) - a1, delta2 =
-// (p - y)/13, delta1 = (13-wide tree of W2 delta2)(1 + a1)(1 - a1) - and to loss_function's
+// (p - y)/classes, delta1 = (class-wide tree of W2 delta2)(1 + a1)(1 - a1) - and to loss_function's
 // value (:559-596); `tr` carries the labels and the outputs, all indexed like pool's rows.
 template <typename T>
 struct FcTrainOut {
-    const int *onehot;    // [nrows][13]
-    T *a1, *d1, *d2;      // [nrows][100], [nrows][100], [nrows][13]
+    const int *onehot;    // [nrows][classes]
+    T *a1, *d1, *d2;      // [nrows][100], [nrows][100], [nrows][classes]
     double *loss_values;  // [nrows]
 };
 
-template <typename T, int MS, bool TRAIN>
+// NO: the class count when it is the reference's 13 (compile-time then), 0 for any other (no_rt).
+template <typename T, int MS, bool TRAIN, int NO>
 __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params, int off_w1, int off_b1,
-                                                   int off_w2, int off_b2, const T *__restrict__ pool,
+                                                   int off_w2, int off_b2, int no_rt, const T *__restrict__ pool,
                                                    int nrows, int pout, T *__restrict__ probs,
                                                    int *__restrict__ argmax, int *__restrict__ ctr,
                                                    FcTrainOut<T> tr)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_next;   // the workgroup's next tile, grabbed one tile ahead
+    const int no = NO ? NO : no_rt;
     typedef FcHeadLds<T, MS> L;
     typedef typename Vec16<T>::type V;
     constexpr int VW = Vec16<T>::W;
@@ -401,9 +403,9 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
 
     issue(0, ra);   // first: the chunk's loads fly while the small operands below are staged
     if (nch > 1) issue(1, rb);
-    stage<6, 256>(params + off_w2, H * O, tid, [&](int e, T v) { w2s[e] = v; });
+    stage<6, 256>(params + off_w2, H * no, tid, [&](int e, T v) { w2s[e] = v; });
     if (tid < H) b1s[tid] = params[off_b1 + tid];
-    if (tid < O) b2s[tid] = params[off_b2 + tid];
+    if (tid < no) b2s[tid] = params[off_b2 + tid];
   for (;;) {   // one tile per iteration; the first chunk of this tile is in wreg / preg
     if (tid == 0) {
         int nx = -1;
@@ -460,13 +462,13 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
     // lane jl producing outputs jl and jl + LS where they exist
     constexpr int LS = 256 / MS;
     const int jl = tid & (LS - 1), s = tid / LS;
-    const int o0 = min(jl, O - 1), o1 = min(jl + LS, O - 1);
-    const bool has0 = jl < O, has1 = jl + LS < O;
+    const int o0 = min(jl, no - 1), o1 = min(jl + LS, no - 1);
+    const bool has0 = jl < no, has1 = jl + LS < no;
     int lab0 = 0, lab1 = 0;
     if (TRAIN) {   // this thread's two labels (clamped, unconditional): in flight during the activations
         const int sl = min(s, nb_done - 1);
-        lab0 = tr.onehot[(long)(r0_done + sl) * O + o0];
-        lab1 = tr.onehot[(long)(r0_done + sl) * O + o1];
+        lab0 = tr.onehot[(long)(r0_done + sl) * no + o0];
+        lab1 = tr.onehot[(long)(r0_done + sl) * no + o1];
     }
     T *z1s = wl;
 #pragma unroll
@@ -485,30 +487,30 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
     if (LS == 8) {
         for (int i = 0; i < H; i++) {
             const T a = zr[i];
-            m0 = m0 + w2s[o0 + i * O] * a;
-            m1 = m1 + w2s[o1 + i * O] * a;
+            m0 = m0 + w2s[o0 + i * no] * a;
+            m1 = m1 + w2s[o1 + i * no] * a;
         }
     } else {
-        for (int i = 0; i < H; i++) m0 = m0 + w2s[o0 + i * O] * zr[i];
+        for (int i = 0; i < H; i++) m0 = m0 + w2s[o0 + i * no] * zr[i];
     }
     const T e0 = rexp(m0 + b2s[o0]), e1 = rexp(m1 + b2s[o1]);
     if (has0) es[s * 16 + o0] = e0;
     if (has1) es[s * 16 + o1] = e1;
     __syncthreads();
-    const T sum = tree13(es + s * 16);
+    const T sum = tree_n(es + s * 16, no);
     const T p0 = e0 / sum, p1 = e1 / sum;
     if (has0) ps[s * 16 + o0] = p0;
     if (has1) ps[s * 16 + o1] = p1;
     if (s < nb_done && probs) {
-        if (has0) probs[(long)(r0_done + s) * O + o0] = p0;
-        if (has1) probs[(long)(r0_done + s) * O + o1] = p1;
+        if (has0) probs[(long)(r0_done + s) * no + o0] = p0;
+        if (has1) probs[(long)(r0_done + s) * no + o1] = p1;
     }
     __syncthreads();
     if (argmax && jl == 0 && s < nb_done) {
         // count_err: running max starts at 0, strict '>' (gcn_mbgd_fp64.cu:636-647)
         T mx = 0;
         int idx = 0;
-        for (int i = 0; i < O; i++)
+        for (int i = 0; i < no; i++)
             if (ps[s * 16 + i] > mx) {
                 mx = ps[s * 16 + i];
                 idx = i;
@@ -518,12 +520,12 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
     if (TRAIN) {
         T *d2s = es;   // the exponentials are dead (every lane holds its probabilities in registers)
         const bool live = s < nb_done;
-        const T dv0 = (p0 - lab0) / O, dv1 = (p1 - lab1) / O;   // gcn_mbgd_fp64.cu:352
+        const T dv0 = (p0 - lab0) / no, dv1 = (p1 - lab1) / no;   // gcn_mbgd_fp64.cu:352
         if (has0) d2s[s * 16 + o0] = dv0;
         if (has1) d2s[s * 16 + o1] = dv1;
         if (live) {
-            if (has0) tr.d2[(long)(r0_done + s) * O + o0] = dv0;
-            if (has1) tr.d2[(long)(r0_done + s) * O + o1] = dv1;
+            if (has0) tr.d2[(long)(r0_done + s) * no + o0] = dv0;
+            if (has1) tr.d2[(long)(r0_done + s) * no + o1] = dv1;
         }
         // the loss terms (an exp and a log each) spread over the sample's lanes, from the labels already
         // in registers; they go to the part of the W1 image that z1s does not use
@@ -539,19 +541,19 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
         }
         __syncthreads();
         if (live) {
-            T dd[O];
+            T dd[OMAX];   // entries past the class count are never read by the tree
 #pragma unroll
-            for (int o = 0; o < O; o++) dd[o] = d2s[s * 16 + o];
+            for (int o = 0; o < OMAX; o++) dd[o] = d2s[s * 16 + o];
             for (int n = jl; n < H; n += LS) {
-                // bp_fully_connect(out -> hidden), gcn_mbgd_fp64.cu:416-434: 13-wide tree
-                T prod[O];
+                // bp_fully_connect(out -> hidden), gcn_mbgd_fp64.cu:416-434: class-wide tree
+                T prod[OMAX];
 #pragma unroll
-                for (int o = 0; o < O; o++) prod[o] = w2s[o + n * O] * dd[o];
+                for (int o = 0; o < OMAX; o++) prod[o] = w2s[min(o, no - 1) + n * no] * dd[o];
                 const T a = zr[n];
                 tr.a1[(long)(r0_done + s) * H + n] = a;
-                tr.d1[(long)(r0_done + s) * H + n] = tree13(prod) * (1 + a) * (1 - a);
+                tr.d1[(long)(r0_done + s) * H + n] = tree_n(prod, no) * (1 + a) * (1 - a);
             }
-            if (jl == LS - 1) tr.loss_values[r0_done + s] = loss_sum(lta + s * 16, ltb + s * 16, labs + s * 16);   // the ordered sum
+            if (jl == LS - 1) tr.loss_values[r0_done + s] = loss_sum(lta + s * 16, ltb + s * 16, labs + s * 16, no);   // the ordered sum
         }
     }
     FC_STAMP(3);
@@ -703,9 +705,13 @@ int forward_impl(const T *params, const T *cubes, long n, int z, T *probs, int *
         }
     }
     if (nwv == 0) return CCNN_E_RANGE;
-    typedef void (*FcKern)(const T *, int, int, int, int, const T *, int, int, T *, int *, int *, FcTrainOut<T>);
-    const FcKern fc32 = train ? fc_head_fwd<T, 32, true> : fc_head_fwd<T, 32, false>;
-    const FcKern fc16 = train ? fc_head_fwd<T, 16, true> : fc_head_fwd<T, 16, false>;
+    typedef void (*FcKern)(const T *, int, int, int, int, int, const T *, int, int, T *, int *, int *, FcTrainOut<T>);
+    constexpr int C13 = CCNN_CLASSES;
+    const bool c13 = d.n_classes == C13;
+    const FcKern fc32 = train ? (c13 ? fc_head_fwd<T, 32, true, C13> : fc_head_fwd<T, 32, true, 0>)
+                              : (c13 ? fc_head_fwd<T, 32, false, C13> : fc_head_fwd<T, 32, false, 0>);
+    const FcKern fc16 = train ? (c13 ? fc_head_fwd<T, 16, true, C13> : fc_head_fwd<T, 16, true, 0>)
+                              : (c13 ? fc_head_fwd<T, 16, false, C13> : fc_head_fwd<T, 16, false, 0>);
     if (int e = allow_smem(fc32, FcHeadLds<T, 32>::bytes)) return e;
     if (int e = allow_smem(fc16, FcHeadLds<T, 16>::bytes)) return e;
     const int fc_res32 = resident_blocks(reinterpret_cast<const void *>(fc32), 256, FcHeadLds<T, 32>::bytes);
@@ -733,8 +739,8 @@ int forward_impl(const T *params, const T *cubes, long n, int z, T *probs, int *
         {
             launch(train ? "fc_head_fwd_train" : "fc_head_fwd", small ? fc16 : fc32, dim3(fg), dim3(256),
                    small ? FcHeadLds<T, 16>::bytes : FcHeadLds<T, 32>::bytes, st,
-                   params, d.off_w1, d.off_b1, d.off_w2, d.off_b2, w.pool, nr, d.pout,
-                   probs ? probs + s0 * O : nullptr, argmax ? argmax + s0 : nullptr, w.ctr,
+                   params, d.off_w1, d.off_b1, d.off_w2, d.off_b2, d.n_classes, w.pool, nr, d.pout,
+                   probs ? probs + s0 * d.n_classes : nullptr, argmax ? argmax + s0 : nullptr, w.ctr,
                    tr ? *tr : FcTrainOut<T>{});
         }
         CCNN_LAUNCH_CHECK();
@@ -748,7 +754,9 @@ template <typename T, bool FLIP>
 int train_forward(const T *params, const T *cubes, const int *onehot, long first, int B, int z, T *pool,
                   unsigned char *px, T *a1, T *d1, T *d2, T *probs, double *loss_values, int *ctr, hipStream_t st)
 {
-    FcTrainOut<T> tr{onehot + first * O, a1, d1, d2, loss_values};
+    ccnn_dims_t d;
+    if (make_dims(z, &d)) return CCNN_E_INVALID;
+    FcTrainOut<T> tr{onehot + first * d.n_classes, a1, d1, d2, loss_values};
     return forward_impl<T, FLIP>(params, cubes, B, z, probs, nullptr, nullptr, 0, st, nullptr, 0, &tr, first, pool, px, ctr);
 }
 template int train_forward<float, true>(const float *, const float *, const int *, long, int, int, float *,

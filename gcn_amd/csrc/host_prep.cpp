@@ -50,8 +50,17 @@ static inline void neighbourhood(int p, int x, int y, int *row)
 int ccnn_host_build_index(const double *labels, const int *data_index, int n, int x, int y,
                           int *train_idx9, int *test_idx9, int *onehot, int *test_labels)
 {
+    return ccnn_host_build_index_classes(labels, data_index, n, x, y, CCNN_CLASSES, train_idx9, test_idx9, onehot,
+                                         test_labels);
+}
+
+int ccnn_host_build_index_classes(const double *labels, const int *data_index, int n, int x, int y, int n_classes,
+                                  int *train_idx9, int *test_idx9, int *onehot, int *test_labels)
+{
     if (!labels || !data_index || !train_idx9 || !test_idx9 || !onehot || !test_labels) return CCNN_E_INVALID;
     if (n <= 0 || x < 2 || y < 2) return CCNN_E_INVALID;
+    if (n_classes < CCNN_MIN_CLASSES || n_classes > CCNN_MAX_CLASSES) return CCNN_E_INVALID;
+    const int O = n_classes;
     int n_train, n_test;
     ccnn_host_split_sizes(n, &n_train, &n_test);
     std::memset(onehot, 0, sizeof(int) * (size_t)n_train * O);
@@ -74,7 +83,14 @@ int ccnn_host_build_index(const double *labels, const int *data_index, int n, in
 
 int ccnn_host_shuffle(int *idx9, int *onehot, int n, unsigned seed)
 {
+    return ccnn_host_shuffle_classes(idx9, onehot, n, CCNN_CLASSES, seed);
+}
+
+int ccnn_host_shuffle_classes(int *idx9, int *onehot, int n, int n_classes, unsigned seed)
+{
     if (!idx9 || !onehot || n < 0) return CCNN_E_INVALID;
+    if (n_classes < CCNN_MIN_CLASSES || n_classes > CCNN_MAX_CLASSES) return CCNN_E_INVALID;
+    const int O = n_classes;
     srand(seed);
     for (int i = 0; i < n; i++) {
         const int j = rand() % (n - i) + i;
@@ -96,8 +112,8 @@ int ccnn_host_init_params_f64(double *params, int z, long pool_bias_draws)
     for (long i = 0; i < d.pin + pool_bias_draws; i++) (void)rand();   // pooling layer's dead tensors
     fill(d.off_w1, d.pout * H);
     fill(d.off_b1, H);
-    fill(d.off_w2, H * O);
-    fill(d.off_b2, O);
+    fill(d.off_w2, H * d.n_classes);
+    fill(d.off_b2, d.n_classes);
     return 0;
 }
 
@@ -111,7 +127,7 @@ int ccnn_host_init_params_f32(float *params, int z)
     fill(d.off_w0, F * K);
     for (long i = 0; i < d.pin; i++) (void)rand();
     fill(d.off_w1, d.pout * H);
-    fill(d.off_w2, H * O);
+    fill(d.off_w2, H * d.n_classes);
     return 0;
 }
 

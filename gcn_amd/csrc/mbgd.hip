@@ -163,7 +163,10 @@ __device__ __forceinline__ void conv_bwd_tiles(const T *cube, const T *delta, in
 // NT threads per workgroup (one workgroup per sample, one per CU): the per-sample chain is
 // latency-bound, and its two walks over W1 are limited by the bytes a CU keeps in flight, so
 // more waves shorten them even though most other phases cannot use the extra threads.
-template <typename T, bool FLIP, int NT>
+// NO: the class count when it is the reference's 13 (a compile-time constant then: the head's
+// loops and its 13-wide tree cost what they cost before the count became a run-time property),
+// 0 for any other count (read from d).
+template <typename T, bool FLIP, int NT, int NO>
 __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ params,
                                                       const T *__restrict__ cubes,
                                                       const int *__restrict__ onehot, long first,
@@ -182,12 +185,12 @@ __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ param
     int *px = reinterpret_cast<int *>(smem + L.px_off);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15;
-    const int re = d.re, mre = d.mre, pout = d.pout;
+    const int re = d.re, mre = d.mre, pout = d.pout, no = NO ? NO : d.n_classes;
     const long row = blockIdx.x;
     FB_TICK(0);
     int *lab = reinterpret_cast<int *>(smem + L.lab_off);
     // the labels are needed deep in the dependent chain: fetch them with the first loads
-    const int lab_g = onehot[(first + row) * O + min(tid, O - 1)];
+    const int lab_g = onehot[(first + row) * no + min(tid, no - 1)];
 
     // ---- forward: conv + tanh + pool ------------------------------------------------
     // Issue every global load this phase needs (filters, cube, and the small output-layer
@@ -208,16 +211,18 @@ __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ param
         wreg[u] = params[d.off_w0 + (e < F * K ? e : F * K - 1)];   // clamped: loads stay unconditional
     }
     const T *W2 = params + d.off_w2;
-    const int o8 = tid >> 3, j8 = tid & 7;   // output layer: 13 outputs x 8 partial sums
-    T w2f[O], w2b[O];
+    const int o8 = tid >> 3, j8 = tid & 7;   // output layer: one output per 8 lanes, 8 partial sums each
+    constexpr int NP8 = (H + 7) / 8;         // products per partial sum
+    T w2f[NP8], w2b[OMAX];
 #pragma unroll
-    for (int k = 0; k < O; k++) {
+    for (int k = 0; k < NP8; k++) {
         const int i = min(j8 + 8 * k, H - 1);   // hidden unit of the k-th partial product
-        w2f[k] = W2[min(o8, O - 1) + i * O];
-        w2b[k] = W2[k + min(tid, H - 1) * O];
+        w2f[k] = W2[min(o8, no - 1) + i * no];
     }
+#pragma unroll
+    for (int k = 0; k < OMAX; k++) w2b[k] = W2[min(k, no - 1) + min(tid, H - 1) * no];   // past the class count: never used
     const T b1v = params[d.off_b1 + min(tid, H - 1)];
-    const T b2v = params[d.off_b2 + min(o8, O - 1)];
+    const T b2v = params[d.off_b2 + min(o8, no - 1)];
     const T bias0 = params[d.off_b0 + col];
     const T bias1 = params[d.off_b0 + min(16 + col, F - 1)];
     FB_TICK(11);
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ param
     // zeros the filter scatter below does not overwrite: the second tile (filters 20..31) and tap 171 of the first
     for (int e = WL_TILE - LDWK + tid; e < WL_LEN; e += NT) wl[e] = 0;
     FB_TICK(12);
-    if (tid < O) lab[tid] = lab_g;   // the first use of a loaded value: after the zeroing, which needs none
+    if (tid < no) lab[tid] = lab_g;   // the first use of a loaded value: after the zeroing, which needs none
     FB_TICK(13);
 #pragma unroll
     for (int u = 0; u < NCREG; u++) {
@@ -330,40 +335,40 @@ __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ param
     {
         T mid = 0;
 #pragma unroll
-        for (int k = 0; k < O; k++) {
+        for (int k = 0; k < NP8; k++) {
             const int i = j8 + 8 * k;
             if (i < H) mid = mid + w2f[k] * a1s[i];
         }
         mid += __shfl_xor(mid, 4);
         mid += __shfl_xor(mid, 2);
         mid += __shfl_xor(mid, 1);
-        if (o8 < O && j8 == 0) es[o8] = rexp(mid + b2v);
+        if (o8 < no && j8 == 0) es[o8] = rexp(mid + b2v);
     }
     __syncthreads();
     FB_TICK(5);
-    if (tid < O) {
-        const T p = es[tid] / tree13(es);
+    if (tid < no) {
+        const T p = es[tid] / tree_n(es, no);
         ps[tid] = p;
-        if (probs_g) probs_g[row * O + tid] = p;
-        const T dv = (p - lab[tid]) / O;   // gcn_mbgd_fp64.cu:352
+        if (probs_g) probs_g[row * no + tid] = p;
+        const T dv = (p - lab[tid]) / no;   // gcn_mbgd_fp64.cu:352
         d2s[tid] = dv;
-        d2_g[row * O + tid] = dv;
+        d2_g[row * no + tid] = dv;
     }
     // the filters are dead: clear their region for the scattered deltas
     for (int e = tid; e < 2 * L.ldd; e += NT) wl[e] = 0;
     __syncthreads();
     FB_TICK(6);
     if (tid < H) {
-        // bp_fully_connect(out -> hidden), gcn_mbgd_fp64.cu:416-434: 13-wide tree
-        T prod[O];
+        // bp_fully_connect(out -> hidden), gcn_mbgd_fp64.cu:416-434: class-wide tree
+        T prod[OMAX];
 #pragma unroll
-        for (int o = 0; o < O; o++) prod[o] = w2b[o] * d2s[o];
-        const T dv = tree13(prod) * (1 + a) * (1 - a);
+        for (int o = 0; o < OMAX; o++) prod[o] = w2b[o] * d2s[o];
+        const T dv = tree_n(prod, no) * (1 + a) * (1 - a);
         d1s[tid] = dv;
         d1_g[row * H + tid] = dv;
     }
     // the loss terms (a log and an exp each) are nobody's input: an idle wave computes them here
-    if (tid >= NT - 64 && tid < NT - 64 + O) {
+    if (tid >= NT - 64 && tid < NT - 64 + no) {
         const int o = tid - (NT - 64);
         loss_terms(ps[o], lab[o], &lta[o], &ltb[o]);
     }
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ param
     return;
 #endif
     // nothing waits for the loss: one thread adds its terms up while the walk below runs
-    if (tid == NT - 1) loss_values[row] = loss_sum(lta, ltb, lab);
+    if (tid == NT - 1) loss_values[row] = loss_sum(lta, ltb, lab, no);
 
     // ---- delta at the pooled features + bp_maxpooling scatter -----------------------
     // dpool[p] = (sum_n W1[n + 100 p] d1[n]) (1 + pool)(1 - pool), gcn_mbgd_fp64.cu:416-434, 450-452
@@ -506,7 +511,7 @@ __device__ __forceinline__ T colsum8(int B, int rg, int c, T *red, Term term)
 // conv-gradient slab, whose row count need not be B) and stores its sums in grad + y * grad_stride;
 // apply_partials then adds the splits in order.  A single 2048-row sum per thread would be 16
 // dependent rounds of loads.
-template <typename T, int KF>
+template <typename T, int KF, int NO>
 __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int off_w1, int off_b1,
                                                           int off_w2, int off_b2,
                                                           const T *__restrict__ pool,
@@ -520,6 +525,7 @@ __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int o
 {
     __shared__ T red[8 * 64];
     const int tid = threadIdx.x;
+    const int no = NO ? NO : (off_b2 - off_w2) / H;   // classes: W2 is [100 x classes]; NO as in sample_fwd_bwd
     int blk = blockIdx.x;
     if (gridDim.y > 1) {
         const int y = blockIdx.y, ny = gridDim.y;
@@ -527,7 +533,7 @@ __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int o
         pool += (long)b_lo * pout;
         a1 += (long)b_lo * H;
         d1 += (long)b_lo * H;
-        d2 += (long)b_lo * O;
+        d2 += (long)b_lo * no;
         B = min(bs, B - b_lo);
         const int ss = (slab_rows + ny - 1) / ny, s_lo = min(y * ss, slab_rows);
         slab_rows = min(ss, slab_rows - s_lo);
@@ -583,10 +589,10 @@ __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int o
                 og[0] = tot;
             }
         } else if (blk < nb_w0 + nb_w2) {
-            const int k = min((blk - nb_w0) * 64 + c, H * O - 1);   // k = o + 13 n
-            const int nn = k / O, o = k - nn * O;
-            const T tot = colsum8<T>(B, rg, c, red, [&](int b) { return a1[(long)b * H + nn] * d2[(long)b * O + o]; });
-            if (rg == 0 && (blk - nb_w0) * 64 + c < H * O) {
+            const int k = min((blk - nb_w0) * 64 + c, H * no - 1);   // k = o + classes * n
+            const int nn = k / no, o = k - nn * no;
+            const T tot = colsum8<T>(B, rg, c, red, [&](int b) { return a1[(long)b * H + nn] * d2[(long)b * no + o]; });
+            if (rg == 0 && (blk - nb_w0) * 64 + c < H * no) {
                 ok[0] = off_w2 + k;
                 og[0] = tot;
             }
@@ -599,9 +605,9 @@ __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int o
                 og[0] = tot;
             }
         } else {
-            const int o = min(c, O - 1);
-            const T tot = colsum8<T>(B, rg, c, red, [&](int b) { return d2[(long)b * O + o]; });
-            if (rg == 0 && c < O) {
+            const int o = min(c, no - 1);
+            const T tot = colsum8<T>(B, rg, c, red, [&](int b) { return d2[(long)b * no + o]; });
+            if (rg == 0 && c < no) {
                 ok[0] = off_b2 + o;
                 og[0] = tot;
             }
@@ -972,7 +978,7 @@ struct MbgdWs {
         size_t b = 0;
         b += align_up((size_t)B * d.pout * sizeof(T));          // pool
         b += 2 * align_up((size_t)B * H * sizeof(T));           // a1, d1
-        b += 2 * align_up((size_t)B * O * sizeof(T));           // d2, probs
+        b += 2 * align_up((size_t)B * d.n_classes * sizeof(T));   // d2, probs
         if (!use_batched(B)) {
             b += align_up((size_t)B * (F * K + F) * sizeof(T));     // per-sample conv gradient tiles
         } else {
@@ -992,8 +998,8 @@ struct MbgdWs {
         pool = c.take<T>((size_t)B * d.pout);
         a1 = c.take<T>((size_t)B * H);
         d1 = c.take<T>((size_t)B * H);
-        d2 = c.take<T>((size_t)B * O);
-        probs = c.take<T>((size_t)B * O);
+        d2 = c.take<T>((size_t)B * d.n_classes);
+        probs = c.take<T>((size_t)B * d.n_classes);
         dp = parts = gsum = nullptr;
         px = nullptr;
         ctr = nullptr;
@@ -1033,7 +1039,7 @@ int launch_grad_reduce(int B, const ccnn_dims_t &d, const MbgdWs<T> &w, int slab
 {
     const int nb_w1 = (d.pout + 15) / 16;
     const int nb_w0 = (F * K + F + 63) / 64;
-    const int nb_w2 = (H * O + 63) / 64;
+    const int nb_w2 = (H * d.n_classes + 63) / 64;
     const int nblocks = nb_w1 + nb_w0 + nb_w2 + 3;
     CommDev xc = {};
     unsigned xstep = 0;
@@ -1044,11 +1050,25 @@ int launch_grad_reduce(int B, const ccnn_dims_t &d, const MbgdWs<T> &w, int slab
             return CCNN_E_RANGE;
         for (int r = 0; r < cm->dev.world; r++)
             if (!cm->dev.peer[r]) return CCNN_E_INVALID;   // not connected
+        if (cm->any_shared) {
+            // Ranks that share a GPU: a batch-sum kernel occupies compute units while it waits for
+            // its peers, and a peer whose per-sample kernel finds no free unit would never get to
+            // answer.  A one-workgroup exchange of one value first: no rank's batch sums start
+            // before every rank's per-sample kernel has finished.
+            void *rdv = cm->dev.peer[cm->dev.rank] + cm->dev.status_off + 64;
+            const int e = cm->elem == 4 ? ccnn_allreduce_f32(cm, static_cast<float *>(rdv), 1, st)
+                                        : ccnn_allreduce_f64(cm, static_cast<double *>(rdv), 1, st);
+            if (e) return e;
+        }
         xc = cm->dev;
         xstep = cm->next_step();
     }
     const bool narrow = sizeof(T) == 8 && cm && cm->shared_device;
-    launch("grad_reduce", narrow ? grad_reduce<T, 16> : grad_reduce<T, 32>, dim3(nblocks, splits), dim3(GR_THREADS), 0, st,
+    const bool c13 = d.n_classes == CCNN_CLASSES;
+    launch("grad_reduce",
+           narrow ? (c13 ? grad_reduce<T, 16, CCNN_CLASSES> : grad_reduce<T, 16, 0>)
+                  : (c13 ? grad_reduce<T, 32, CCNN_CLASSES> : grad_reduce<T, 32, 0>),
+           dim3(nblocks, splits), dim3(GR_THREADS), 0, st,
            B, d.pout, d.off_w1, d.off_b1, d.off_w2, d.off_b2, w.pool, w.a1, w.d1, w.d2, w.slab, slab_rows, nb_w1, nb_w0,
            nb_w2, grad, grad_stride, upd, xc, xstep);
     CCNN_LAUNCH_CHECK();
@@ -1113,9 +1133,11 @@ int mbgd_impl(const T *params, const T *cubes, const int *onehot, long first, in
     MbgdWs<T> w(ws, B, d);
     if (use_batched(B)) return mbgd_batched<T, FLIP>(params, cubes, onehot, first, B, z, d, grad, upd, loss_values, probs, w, st, cm);
     const FusedLayout L = fused_layout<T>(d.re, d.mre);
-    if (int e = allow_smem(sample_fwd_bwd<T, FLIP, FB_THREADS>, L.bytes)) return e;
+    const auto fb = d.n_classes == CCNN_CLASSES ? sample_fwd_bwd<T, FLIP, FB_THREADS, CCNN_CLASSES>
+                                                : sample_fwd_bwd<T, FLIP, FB_THREADS, 0>;
+    if (int e = allow_smem(fb, L.bytes)) return e;
     {
-        launch("sample_fwd_bwd", sample_fwd_bwd<T, FLIP, FB_THREADS>, dim3(B), dim3(FB_THREADS), L.bytes, st, params, cubes, onehot, first,
+        launch("sample_fwd_bwd", fb, dim3(B), dim3(FB_THREADS), L.bytes, st, params, cubes, onehot, first,
                d, w.pool, w.a1, w.d1, w.d2, probs, loss_values, w.slab);
     }
     CCNN_LAUNCH_CHECK();

@@ -44,20 +44,6 @@ struct SgdWs {
     }
 };
 
-__device__ __forceinline__ double tree13d(const double *v)
-{
-    double t[O];
-#pragma unroll
-    for (int i = 0; i < O; i++) t[i] = v[i];
-#pragma unroll
-    for (int i = 0; i < 6; i++) t[i] = t[i] + t[i + 7];
-#pragma unroll
-    for (int i = 0; i < 3; i++) t[i] = t[i] + t[i + 4];
-    t[0] = t[0] + t[2];
-    t[1] = t[1] + t[3];
-    return t[0] + t[1];
-}
-
 // LDS carve (doubles, then ints)
 struct SgdLds {
     int cube, w, a0, pl, dp, w1, w2, b1, b2, z1, a1, d1, es, ps, d2, b0, total;
@@ -73,7 +59,7 @@ __host__ __device__ inline SgdLds sgd_lds(const ccnn_dims_t &d)
     L.pl = o;   o += d.mre + 1;
     L.dp = o;   o += d.mre + 1;
     L.w1 = o;   o += d.mre * H;
-    L.w2 = o;   o += H * O;
+    L.w2 = o;   o += H * OMAX;
     L.b1 = o;   o += H;
     L.b2 = o;   o += 16;
     L.z1 = o;   o += H;
@@ -89,6 +75,8 @@ __host__ __device__ inline SgdLds sgd_lds(const ccnn_dims_t &d)
     return L;
 }
 
+// NO: 13 when the class count is the reference's (compile-time then), 0 for any other (d.n_classes).
+template <int NO>
 __global__ __launch_bounds__(SGD_THREADS) void sgd_epoch(double *__restrict__ params,
                                                          const double *__restrict__ cubes,
                                                          const int *__restrict__ onehot, long first, long count,
@@ -106,16 +94,16 @@ __global__ __launch_bounds__(SGD_THREADS) void sgd_epoch(double *__restrict__ pa
     double *b0s = base + L.b0;
     int *px = reinterpret_cast<int *>(smem + L.px_off);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int re = d.re, mre = d.mre, cube_len = d.cube;
+    const int re = d.re, mre = d.mre, cube_len = d.cube, no = NO ? NO : d.n_classes;
     double *W1g = params + d.off_w1 + (long)f * mre * H;
 
     // ---- residents: filter, W1 slice, head replica -----------------------------------------
     if (tid < K) w[tid] = params[f * K + tid];
     if (tid >= K && tid < 192) w[tid] = 0;   // taps 171..191 read as zero by the 3-taps-per-lane conv
     for (int e = tid; e < mre * H; e += SGD_THREADS) w1[e] = W1g[e];
-    for (int e = tid; e < H * O; e += SGD_THREADS) w2[e] = params[d.off_w2 + e];
+    for (int e = tid; e < H * no; e += SGD_THREADS) w2[e] = params[d.off_w2 + e];
     if (tid < H) b1[tid] = params[d.off_b1 + tid];
-    if (tid < O) b2[tid] = params[d.off_b2 + tid];
+    if (tid < no) b2[tid] = params[d.off_b2 + tid];
     if (tid == 0) b0s[0] = params[d.off_b0 + f];
     for (int e = cube_len + tid; e < cube_len + 32; e += SGD_THREADS) cube[e] = 0;   // pad read by taps 171..191
     double loss_acc = (first == 0) ? 0.0 : *loss;   // used by one thread of workgroup 0
@@ -137,7 +125,7 @@ __global__ __launch_bounds__(SGD_THREADS) void sgd_epoch(double *__restrict__ pa
 
     for (long i = 0; i < count; i++) {
         const long s = first + i;
-        const int *lab = onehot + s * O;
+        const int *lab = onehot + s * no;
         __syncthreads();   // the previous sample's readers of cube / pl / dp / d1s are done
 #pragma unroll
         for (int u = 0; u < SGD_NREG; u++) {
@@ -242,30 +230,30 @@ __global__ __launch_bounds__(SGD_THREADS) void sgd_epoch(double *__restrict__ pa
         __syncthreads();
         if (wave == 0) {
             // one wave, no workgroup barrier inside: output o = lane >> 2 sums its 100-term dot
-            // product in 4 interleaved parts, then every lane rebuilds the 13-wide tree
-            const int o4 = min(lane >> 2, O - 1), j4 = lane & 3;
+            // product in 4 interleaved parts, then every lane rebuilds the class-wide tree
+            const int o4 = min(lane >> 2, no - 1), j4 = lane & 3;
             double mid = 0;
-            for (int n = j4; n < H; n += 4) mid = mid + w2[o4 + n * O] * a1s[n];
+            for (int n = j4; n < H; n += 4) mid = mid + w2[o4 + n * no] * a1s[n];
             mid += __shfl_xor(mid, 2);
             mid += __shfl_xor(mid, 1);
             const double e = exp(mid + b2[o4]);
-            double ev[O];
+            double ev[OMAX];
 #pragma unroll
-            for (int k = 0; k < O; k++) ev[k] = __shfl(e, 4 * k);
-            const double p = e / tree13d(ev);
-            if (lane < 4 * O && j4 == 0) {
+            for (int k = 0; k < OMAX; k++) ev[k] = __shfl(e, 4 * k);
+            const double p = e / tree_n(ev, no);
+            if (lane < 4 * no && j4 == 0) {
                 ps[o4] = p;
-                d2s[o4] = (p - lab[o4]) / O;
+                d2s[o4] = (p - lab[o4]) / no;
             }
         }
         __syncthreads();
         if (tid < H) {
-            double prod[O];
+            double prod[OMAX];
 #pragma unroll
-            for (int o = 0; o < O; o++) prod[o] = w2[o + tid * O] * d2s[o];
-            d1s[tid] = tree13d(prod) * (1 + a) * (1 - a);
+            for (int o = 0; o < OMAX; o++) prod[o] = w2[min(o, no - 1) + tid * no] * d2s[o];
+            d1s[tid] = tree_n(prod, no) * (1 + a) * (1 - a);
         }
-        if (f == 0 && wave == SGD_WAVES - 1 && lane < O)   // loss terms in parallel (output_and_loss, :343-365)
+        if (f == 0 && wave == SGD_WAVES - 1 && lane < no)   // loss terms in parallel (output_and_loss, :343-365)
             lt[lane] = lab[lane] * log(ps[lane]) + (1 - lab[lane]) * log(1 - ps[lane]);
         __syncthreads();
         SGD_TICK(3);
@@ -305,8 +293,8 @@ __global__ __launch_bounds__(SGD_THREADS) void sgd_epoch(double *__restrict__ pa
                 for (int m = 0; m < mre; m++) mid1 = mid1 + dp[m] * (1 + pl[m]) * (1 - pl[m]);
                 b0s[0] = b0s[0] - lr * (mid1 / re);
             } else if (lane == 1) {
-                if (f == 0) loss_acc = loss_acc - tree13d(lt) / O;
-            } else if (lane >= 16 && lane < 16 + O) {
+                if (f == 0) loss_acc = loss_acc - tree_n(lt, no) / no;
+            } else if (lane >= 16 && lane < 16 + no) {
                 b2[lane - 16] = b2[lane - 16] - lr * d2s[lane - 16];
             }
             b1[lane] = b1[lane] - lr * d1s[lane];
@@ -324,13 +312,14 @@ __global__ __launch_bounds__(SGD_THREADS) void sgd_epoch(double *__restrict__ pa
                     m++;
                 }
             }
-            int hn = t4 / O, ho = t4 - hn * O;
-            for (int e = t4; e < H * O; e += 256) {
+            int hn = t4 / no, ho = t4 - hn * no;
+            const int step_n = 256 / no, step_o = 256 - step_n * no;   // 256 = 19 * 13 + 9 for 13 classes
+            for (int e = t4; e < H * no; e += 256) {
                 w2[e] = w2[e] - lr * a1s[hn] * d2s[ho];
-                ho += 9;     // 256 = 19 * 13 + 9
-                hn += 19;
-                if (ho >= O) {
-                    ho -= O;
+                ho += step_o;
+                hn += step_n;
+                if (ho >= no) {
+                    ho -= no;
                     hn++;
                 }
             }
@@ -348,9 +337,9 @@ __global__ __launch_bounds__(SGD_THREADS) void sgd_epoch(double *__restrict__ pa
     for (int e = tid; e < mre * H; e += SGD_THREADS) W1g[e] = w1[e];
     if (tid == 0) params[d.off_b0 + f] = b0s[0];
     if (f == 0) {
-        for (int e = tid; e < H * O; e += SGD_THREADS) params[d.off_w2 + e] = w2[e];
+        for (int e = tid; e < H * no; e += SGD_THREADS) params[d.off_w2 + e] = w2[e];
         if (tid < H) params[d.off_b1 + tid] = b1[tid];
-        if (tid < O) params[d.off_b2 + tid] = b2[tid];
+        if (tid < no) params[d.off_b2 + tid] = b2[tid];
         // a workgroup that gave up waiting (never expected: see the residency check on the host)
         // leaves a partly trained model behind: the loss says so instead of looking like a result
         if (tid == 3 * 64 + 1) *loss = aborted ? __longlong_as_double(0x7ff8000000000000ll) : loss_acc;
@@ -385,12 +374,13 @@ int ccnn_sgd_f64(double *params, const double *cubes, const int *onehot, long fi
     hipError_t e = hipMemsetAsync(workspace, 0, SgdWs::bytes(), st);
     if (e != hipSuccess) return (int)e;
     const SgdLds L = sgd_lds(d);
-    int rc = allow_smem(sgd_epoch, L.bytes);
+    const auto kern = d.n_classes == CCNN_CLASSES ? sgd_epoch<CCNN_CLASSES> : sgd_epoch<0>;
+    int rc = allow_smem(kern, L.bytes);
     if (rc) return rc;
     // the 20 worker workgroups wait for each other inside the launch: every workgroup of the grid
     // must be resident at once (a device with masked or too few CUs cannot run this kernel)
-    if (resident_blocks(reinterpret_cast<const void *>(sgd_epoch), SGD_THREADS, L.bytes) < F * SGD_XCD_STRIDE) return CCNN_E_RANGE;
-    launch("sgd_epoch", sgd_epoch, dim3(F * SGD_XCD_STRIDE), dim3(SGD_THREADS), L.bytes, st, params, cubes, onehot, first,
+    if (resident_blocks(reinterpret_cast<const void *>(kern), SGD_THREADS, L.bytes) < F * SGD_XCD_STRIDE) return CCNN_E_RANGE;
+    launch("sgd_epoch", kern, dim3(F * SGD_XCD_STRIDE), dim3(SGD_THREADS), L.bytes, st, params, cubes, onehot, first,
            count, d, lr, loss, ws);
     CCNN_LAUNCH_CHECK();
     return 0;

@@ -18,7 +18,12 @@ class CcnnError(RuntimeError):
 class Dims(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "z", "cube", "re", "mre", "pin", "pout",
-        "off_w0", "off_b0", "off_w1", "off_b1", "off_w2", "off_b2", "nparams")]
+        "off_w0", "off_b0", "off_w1", "off_b1", "off_w2", "off_b2", "nparams", "n_classes")]
+
+
+def geometry(z, n_classes=CLASSES):
+    """What the entry points take as `z` when the class count is not 13 (CCNN_GEOMETRY)."""
+    return int(z) | (int(n_classes) << 16) if n_classes != CLASSES else int(z)
 
 
 class LrSched(C.Structure):
@@ -58,6 +63,8 @@ _SIG = {
     "ccnn_host_split_sizes": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ccnn_host_build_index": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "ccnn_host_shuffle": (C.c_int, [_P, _P, C.c_int, C.c_uint]),
+    "ccnn_host_build_index_classes": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "ccnn_host_shuffle_classes": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_uint]),
     "ccnn_host_init_params_f64": (C.c_int, [_P, C.c_int, C.c_long]),
     "ccnn_host_init_params_f32": (C.c_int, [_P, C.c_int]),
     "ccnn_host_sched_init": (C.c_int, [C.POINTER(LrSched), C.c_double, C.c_int]),

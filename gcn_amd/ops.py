@@ -117,13 +117,14 @@ class GatherPlan:
 
 
 def forward(params, cubes, z, want_probs=True, want_argmax=True, workspace=None):
-    """Test-loop forward over cubes [n, 9z] -> (probs [n,13] | None, argmax int32 [n] | None)."""
+    """Test-loop forward over cubes [n, 9z] -> (probs [n, classes] | None, argmax int32 [n] | None).
+    z: the band count, or lib.geometry(z, n_classes) for a class count other than 13 (here and below)."""
     sfx, es = _sfx(params.dtype)
     d = _l.dims(z)
     _req(params, params.dtype, "params", d.nparams)
     n = cubes.numel() // d.cube
     _req(cubes, params.dtype, "cubes", n * d.cube)
-    probs = torch.empty((n, 13), dtype=params.dtype, device=params.device) if want_probs else None
+    probs = torch.empty((n, d.n_classes), dtype=params.dtype, device=params.device) if want_probs else None
     argmax = torch.empty(n, dtype=torch.int32, device=params.device) if want_argmax else None
     if n == 0:
         return probs, argmax
@@ -141,12 +142,12 @@ def forward_scene(params, scene, idx9, x, y, z, want_probs=True, want_argmax=Tru
     sfx, es = _sfx(params.dtype)
     d = _l.dims(z)
     _req(params, params.dtype, "params", d.nparams)
-    _req(scene, params.dtype, "scene", x * y * z)
+    _req(scene, params.dtype, "scene", x * y * d.z)
     _req(idx9, torch.int32, "idx9")
     n = idx9.numel() // 9
     if idx9.numel() != n * 9:
         raise ValueError("idx9 must hold 9 indices per sample")
-    probs = torch.empty((n, 13), dtype=params.dtype, device=params.device) if want_probs else None
+    probs = torch.empty((n, d.n_classes), dtype=params.dtype, device=params.device) if want_probs else None
     argmax = torch.empty(n, dtype=torch.int32, device=params.device) if want_argmax else None
     if n == 0:
         return probs, argmax
@@ -175,7 +176,7 @@ def sgd(params, cubes, onehot, first, count, z, lr, loss, workspace=None):
     _req(params, _F64, "params", d.nparams)
     n = cubes.numel() // d.cube
     _req(cubes, _F64, "cubes", n * d.cube)
-    _req(onehot, torch.int32, "onehot", n * 13)
+    _req(onehot, torch.int32, "onehot", n * d.n_classes)
     _req(loss, _F64, "loss", 1)
     if first < 0 or count < 0 or first + count > n:
         raise ValueError(f"samples [{first}, {first + count}) outside [0, {n})")
@@ -192,7 +193,7 @@ def mbgd_grad(params, cubes, onehot, first, B, z, grad=None, loss_values=None, p
     _req(params, params.dtype, "params", d.nparams)
     n = cubes.numel() // d.cube
     _req(cubes, params.dtype, "cubes", n * d.cube)
-    _req(onehot, torch.int32, "onehot", n * 13)
+    _req(onehot, torch.int32, "onehot", n * d.n_classes)
     if B <= 0 or first < 0 or first + B > n:
         raise ValueError(f"batch [{first}, {first + B}) outside [0, {n})")
     if grad is None:
@@ -204,7 +205,7 @@ def mbgd_grad(params, cubes, onehot, first, B, z, grad=None, loss_values=None, p
     if loss_values.numel() < B:
         raise ValueError("loss_values shorter than the batch")
     if probs is not None:
-        _req(probs, params.dtype, "probs", B * 13)
+        _req(probs, params.dtype, "probs", B * d.n_classes)
     lib = _l.load()
     ws = (workspace or Workspace(params.device)).get(lib.ccnn_mbgd_workspace_bytes(B, z, es))
     fn = getattr(lib, f"ccnn_mbgd_grad_{sfx}")
@@ -223,7 +224,7 @@ def mbgd_step(params, cubes, onehot, first, B, z, lr, loss_values=None, workspac
     _req(params, params.dtype, "params", d.nparams)
     n = cubes.numel() // d.cube
     _req(cubes, params.dtype, "cubes", n * d.cube)
-    _req(onehot, torch.int32, "onehot", n * 13)
+    _req(onehot, torch.int32, "onehot", n * d.n_classes)
     if B <= 0 or first < 0 or first + B > n:
         raise ValueError(f"batch [{first}, {first + B}) outside [0, {n})")
     if loss_values is None:

@@ -30,24 +30,27 @@ def split_sizes(n):
     return tr.value, te.value
 
 
-def build_index(labels, data_index, x, y):
-    """-> train_idx9 [tr,9], test_idx9 [te,9], onehot [tr,13], test_labels [te] (all int32)."""
+def build_index(labels, data_index, x, y, n_classes=_l.CLASSES):
+    """-> train_idx9 [tr,9], test_idx9 [te,9], onehot [tr,n_classes], test_labels [te] (all int32)."""
     labels = np.ascontiguousarray(labels, dtype=np.float64).ravel()
     data_index = np.ascontiguousarray(data_index, dtype=np.int32)
     tr, te = split_sizes(len(data_index))
     train_idx9 = np.empty((tr, 9), dtype=np.int32)
     test_idx9 = np.empty((te, 9), dtype=np.int32)
-    onehot = np.empty((tr, 13), dtype=np.int32)
+    onehot = np.empty((tr, n_classes), dtype=np.int32)
     test_labels = np.empty(te, dtype=np.int32)
-    _l.check(_l.load().ccnn_host_build_index(_p(labels), _p(data_index), len(data_index), x, y, _p(train_idx9),
-                                             _p(test_idx9), _p(onehot), _p(test_labels)), "ccnn_host_build_index")
+    _l.check(_l.load().ccnn_host_build_index_classes(_p(labels), _p(data_index), len(data_index), x, y, n_classes,
+                                                     _p(train_idx9), _p(test_idx9), _p(onehot), _p(test_labels)),
+             "ccnn_host_build_index_classes")
     return train_idx9, test_idx9, onehot, test_labels
 
 
 def shuffle(idx9, onehot, seed):
     """In place; seeds libc rand() with `seed` and leaves the stream for init_params."""
     assert idx9.dtype == np.int32 and onehot.dtype == np.int32 and idx9.flags.c_contiguous and onehot.flags.c_contiguous
-    _l.check(_l.load().ccnn_host_shuffle(_p(idx9), _p(onehot), len(idx9), C.c_uint(seed)), "ccnn_host_shuffle")
+    n_classes = onehot.shape[1] if onehot.ndim == 2 else _l.CLASSES
+    _l.check(_l.load().ccnn_host_shuffle_classes(_p(idx9), _p(onehot), len(idx9), n_classes, C.c_uint(seed)),
+             "ccnn_host_shuffle_classes")
 
 
 def init_params(z, dtype, pool_bias_draws=0):

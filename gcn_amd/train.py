@@ -216,16 +216,20 @@ def evaluate(params, cubes, test_labels, z):
     return ops.count_correct(am, test_labels).item() / n
 
 
-def prepare(scene, labels, x, y, z, dtype, seed, pool_bias_draws=None, device="cuda"):
+def prepare(scene, labels, x, y, z, dtype, seed, pool_bias_draws=None, device="cuda", n_classes=13):
     """The reference's prologue: scan, split, neighbour lists, shuffle, H2D, gather, init.
-    scene: flat [z][y][x] numpy array; labels: x*y float64.  Returns a dict of device tensors."""
+    scene: flat [z][y][x] numpy array; labels: x*y float64.  Returns a dict of device tensors;
+    its "geometry" is what the training and inference calls take as `z` (the band count itself
+    for the reference's 13 classes)."""
+    from . import lib as _l
     npdt = np.float32 if dtype == torch.float32 else np.float64
     di = prep.scan_labels(labels, x, y)
-    tr9, te9, onehot, test_labels = prep.build_index(labels, di, x, y)
+    tr9, te9, onehot, test_labels = prep.build_index(labels, di, x, y, n_classes)
     prep.shuffle(tr9, onehot, seed)
-    d = __import__("gcn_amd.lib", fromlist=["dims"]).dims(z)
+    geom = _l.geometry(z, n_classes)
+    d = _l.dims(geom)
     draws = d.pout if pool_bias_draws is None else pool_bias_draws
-    params = prep.init_params(z, npdt, draws)
+    params = prep.init_params(geom, npdt, draws)
     scene_d = torch.from_numpy(np.ascontiguousarray(scene, dtype=npdt)).to(device)
     out = dict(
         train_cubes=ops.gather(scene_d, torch.from_numpy(tr9).to(device), x, y, z),
@@ -233,6 +237,6 @@ def prepare(scene, labels, x, y, z, dtype, seed, pool_bias_draws=None, device="c
         onehot=torch.from_numpy(onehot).to(device),
         test_labels=torch.from_numpy(test_labels).to(device),
         params=torch.from_numpy(params).to(device),
-        train_idx9=tr9, test_idx9=te9,
+        train_idx9=tr9, test_idx9=te9, geometry=geom,
     )
     return out

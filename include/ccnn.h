@@ -25,7 +25,7 @@
  *           (MATLAB column-major x-by-y-by-z array, gcn_sgd_fp64.cu:481)
  *   idx9    [n][9] int32 linear pixel indices r + c*x (gcn_sgd_fp64.cu:601-626)
  *   cubes   [n][z][9]: sample i, band b, neighbour j at i*9z + b*9 + j
- *   onehot  [n][13] int32
+ *   onehot  [n][13] int32 (n_classes wide: see CCNN_GEOMETRY)
  *   params  flat vector, ccnn_dims_t gives the offsets:
  *           W0[f*171 + tap] | b0[20] | W1[n + 100*p] | b1[100] | W2[o + 13*n] | b2[13]
  *           (the order hyper_version_mGPU_MBGD.cu:966-976 broadcasts them in;
@@ -46,7 +46,9 @@ extern "C" {
 #define CCNN_STRIDE 2        /* STRIDE       :15 */
 #define CCNN_POOL_LEN 2      /* POOLONG_LEN  :16 */
 #define CCNN_HIDDEN 100      /* NEU_NUM1     :17 */
-#define CCNN_CLASSES 13      /* NEU_NUM2     :18 */
+#define CCNN_CLASSES 13      /* NEU_NUM2     :18: the class count unless the caller names another */
+#define CCNN_MIN_CLASSES 2
+#define CCNN_MAX_CLASSES 16  /* the output layer stays inside one 16-wide tile */
 #define CCNN_PER_LAYER 9     /* NEIGHBOR + 1 :19 */
 #define CCNN_FILTER_SIZE 171 /* (NEIGHBOR+1)*COV_LEN */
 
@@ -58,9 +60,17 @@ extern "C" {
 #define CCNN_MIN_BANDS 21    /* at least one convolution output */
 #define CCNN_MAX_BANDS 448     /* whole cube + filters stay under 64 KB of LDS in fp64 */
 
+/* The class count is a compile-time constant of the reference (NEU_NUM2 = 13, one build per
+ * data set).  Here it is a run-time property of the network, 2..16: wherever an entry point
+ * takes the band count `z`, a caller with a class count other than 13 passes
+ * CCNN_GEOMETRY(z, n_classes) instead (a plain band count means 13 classes, as in the
+ * reference).  onehot / probs rows are then n_classes wide and W2 / b2 sized to match. */
+#define CCNN_GEOMETRY(z, n_classes) ((z) | ((n_classes) << 16))
+
 typedef struct ccnn_dims {
     int z, cube, re, mre, pin, pout;
     int off_w0, off_b0, off_w1, off_b1, off_w2, off_b2, nparams;
+    int n_classes;
 } ccnn_dims_t;
 
 /* Derived sizes of the network for z bands (gcn_sgd_fp64.cu:726-737). Host only. */
@@ -232,15 +242,22 @@ int ccnn_host_split_sizes(int n_labelled, int *n_train, int *n_test);
  * order (r-1,c-1) (r,c-1) (r+1,c-1) (r-1,c) ... (r+1,c+1) with out-of-scene
  * neighbours mirrored about the centre pixel.  onehot [n_train][13] (zeroed
  * here), test_labels [n_test].  Needs x >= 2 and y >= 2 (the reference indexes
- * outside the scene otherwise) and labels in 0..13. */
+ * outside the scene otherwise) and labels in 0..13 (CCNN_E_INVALID otherwise). */
 int ccnn_host_build_index(const double *labels, const int *data_index, int n_labelled, int x, int y,
                           int *train_idx9, int *test_idx9, int *onehot, int *test_labels);
+/* The same with n_classes (2..16) instead of 13: onehot [n_train][n_classes], labels in
+ * 1..n_classes.  The reference fixes the count at compile time (NEU_NUM2, gcn_sgd_fp64.cu:18). */
+int ccnn_host_build_index_classes(const double *labels, const int *data_index, int n_labelled, int x,
+                                  int y, int n_classes, int *train_idx9, int *test_idx9, int *onehot,
+                                  int *test_labels);
 
 /* Fisher-Yates over the training rows with libc rand(): srand(seed), then for
  * i: j = rand() % (n-i) + i, swap rows i and j of idx9 and onehot
  * (gcn_sgd_fp64.cu:526-547, whose seed is time(NULL)).  Leaves the rand() stream
  * where the reference's weight initialisation continues it. */
 int ccnn_host_shuffle(int *idx9, int *onehot, int n_train, unsigned seed);
+/* The same for onehot rows n_classes wide. */
+int ccnn_host_shuffle_classes(int *idx9, int *onehot, int n_train, int n_classes, unsigned seed);
 
 /* Initial weights from the current libc rand() stream, in the reference's draw
  * order (Layer constructors, gcn_sgd_fp64.cu:765-768, gcn_mbgd_fp64.cu:904-910,

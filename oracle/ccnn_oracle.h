@@ -23,7 +23,9 @@ extern "C" {
 #define ORC_STRIDE 2
 #define ORC_POOL_LEN 2
 #define ORC_HIDDEN 100
+#ifndef ORC_CLASSES   /* NEU_NUM2: a reference user with another class count rebuilds with another value; so does the Makefile (-DORC_CLASSES=16) */
 #define ORC_CLASSES 13
+#endif
 #define ORC_NEIGHBOR 8
 #define ORC_PER_LAYER (ORC_NEIGHBOR + 1)
 #define ORC_FILTER_SIZE (ORC_PER_LAYER * ORC_COV_LEN)

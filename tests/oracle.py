@@ -11,9 +11,11 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
-_LIB_PATH = os.path.join(_ORACLE_DIR, "_build", "libccnn_oracle.so")
+_LIB_PATHS = {13: os.path.join(_ORACLE_DIR, "_build", "libccnn_oracle.so"),
+              16: os.path.join(_ORACLE_DIR, "_build", "libccnn_oracle_c16.so"),   # the oracle compiled with ORC_CLASSES=16
+              9: os.path.join(_ORACLE_DIR, "_build", "libccnn_oracle_c9.so")}
 
-FILTERS, COV_LEN, STRIDE, POOL_LEN, HIDDEN, CLASSES, PER_LAYER = 20, 19, 2, 2, 100, 13, 9
+FILTERS, COV_LEN, STRIDE, POOL_LEN, HIDDEN, PER_LAYER = 20, 19, 2, 2, 100, 9
 FILTER_SIZE = PER_LAYER * COV_LEN
 
 
@@ -32,24 +34,44 @@ class SchedF32(C.Structure):
 
 
 def build():
-    """Compile the oracle if the shared object is missing or stale."""
-    srcs = [os.path.join(_ORACLE_DIR, f) for f in ("ccnn_oracle.c", "ccnn_kernels.inc", "ccnn_oracle.h")]
-    if os.path.exists(_LIB_PATH) and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs):
-        return _LIB_PATH
-    subprocess.check_call(["make", "-C", _ORACLE_DIR, "-s"])
-    return _LIB_PATH
+    """Compile the oracle (both class counts) if a shared object is missing or stale."""
+    srcs = [os.path.join(_ORACLE_DIR, f) for f in ("ccnn_oracle.c", "ccnn_kernels.inc", "ccnn_oracle.h", "Makefile")]
+    fresh = all(os.path.exists(p) and all(os.path.getmtime(p) >= os.path.getmtime(s) for s in srcs)
+                for p in _LIB_PATHS.values())
+    if not fresh:
+        subprocess.check_call(["make", "-C", _ORACLE_DIR, "-s"])
+    return _LIB_PATHS[13]
 
 
-_lib = None
+_libs = {}
+CLASSES = 13          # the class count of the oracle build in use (see use_classes)
 
 
 def lib():
-    global _lib
-    if _lib is None:
-        _lib = C.CDLL(build())
-        _lib.orc_mgpu_step_f64.restype = C.c_double
-        _lib.orc_mgpu_first_sample.restype = C.c_long
-    return _lib
+    if CLASSES not in _libs:
+        build()
+        l = C.CDLL(_LIB_PATHS[CLASSES])
+        l.orc_mgpu_step_f64.restype = C.c_double
+        l.orc_mgpu_first_sample.restype = C.c_long
+        _libs[CLASSES] = l
+    return _libs[CLASSES]
+
+
+class use_classes:
+    """`with oracle.use_classes(16):` - every call inside goes to the oracle built with that class count."""
+
+    def __init__(self, n):
+        assert n in _LIB_PATHS, n
+        self.n = n
+
+    def __enter__(self):
+        global CLASSES
+        self.prev, CLASSES = CLASSES, self.n
+        return self
+
+    def __exit__(self, *exc):
+        global CLASSES
+        CLASSES = self.prev
 
 
 def _p(a, ct):

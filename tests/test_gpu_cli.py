@@ -181,3 +181,37 @@ def test_argument_errors(tmp_path):
     assert r.returncode == 0 and "3 input arguments required!" in r.stderr      # gcn_mbgd_fp64.cu:1269-1272
     r = subprocess.run([GCN, "missing.mat", "0"], cwd=tmp_path, capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "cannot open" in r.stderr
+
+
+@pytest.mark.parametrize("variant,dtype,lr,fifo,explicit", [("mbgd_fp32", np.float32, 0.04, 100.0, False),
+                                                            ("mbgd_fp64", np.float64, 0.5, 1.0, True),
+                                                            ("sgd_fp64", np.float64, 0.008, 1.0, False)])
+def test_sixteen_class_label_map_trains(tmp_path, variant, dtype, lr, fifo, explicit):
+    """A label map with 16 classes (the reference needs NEU_NUM2 = 16 and a rebuild; the oracle is
+    that rebuild): picked up from the labels or given with --classes=16; losses, weights, model.mat
+    shapes and accuracy against the oracle's replay."""
+    scene, labels = synth.small_scene(X, Y, Z, 3)
+    rng = np.random.default_rng(8)
+    lab16 = np.where(labels > 0, rng.integers(1, 17, labels.size), 0).astype(labels.dtype)
+    assert lab16.max() == 16
+    if explicit:                     # no label above 13 left: only the option can say 16
+        lab16 = np.where(lab16 > 13, lab16 - 3, lab16)
+    ds = scene.reshape(Z, Y, X).transpose(2, 1, 0).astype(dtype)
+    path = str(tmp_path / "DATASET16.mat")
+    sio.savemat(path, {"DataSet": ds, "labels": lab16.reshape(Y, X).T}, do_compression=True)
+    sgd = variant == "sgd_fp64"
+    B, epochs = (1, 2) if sgd else (20, 3)
+    args = [f"--variant={variant}", f"--seed={SEED}", f"--epochs={epochs}"] + ([] if sgd else [f"--batch={B}"])
+    out = run_gcn(tmp_path, args + (["--classes=16"] if explicit else []) + [path, "0"])
+    with orc.use_classes(16):
+        p_ref, l_ref, acc_ref, d = oracle_run(scene, lab16, dtype, B, lr, epochs, sgd=sgd, fifo=fifo)
+    losses, acc_line, _ = parse(out)
+    assert np.allclose(losses, l_ref, rtol=2e-5, atol=1e-6)
+    assert abs(float(acc_line.split(" ")[9].rstrip("%")) - 100 * acc_ref) <= 0.1 + 1e-9
+    names = (("filters", "conv_bias", "fulconnect_weights", "fulconnect_bias", "output_weights", "output_bias") if sgd
+             else ("filters", "bias0", "omega1", "bias1", "omega2", "bias2"))
+    m = sio.loadmat(str(tmp_path / ("model.mat" if sgd else os.path.join("model", "model.mat"))))
+    assert m[names[4]].shape == (16, 100) and m[names[5]].shape == (16, 1)
+    got = np.concatenate([m[k].ravel(order="F") for k in names])
+    tol = 1e-5 if dtype == np.float32 else 1e-10
+    assert np.abs(got - p_ref).max() <= tol * np.abs(p_ref).max()

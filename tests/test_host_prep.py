@@ -4,6 +4,7 @@ import pytest
 
 import oracle as orc
 import synth
+from gcn_amd import lib as L
 from gcn_amd import prep
 
 
@@ -91,3 +92,41 @@ def test_partition_matches_reference_slices(golden):
     for r in range(n):
         first, sub = prep.partition(T, B, n, r, T // B - 1)
         assert sub == 12 and r * (T // n) <= first and first + sub <= (r + 1) * (T // n)
+
+
+@pytest.mark.parametrize("classes", [16, 9])
+def test_other_class_counts_match_the_oracle_rebuilt_for_them(classes):
+    """Run-time class count (CCNN_GEOMETRY, ccnn_host_*_classes) against the oracle compiled with the
+    same NEU_NUM2 (a compile-time constant of the reference, gcn_sgd_fp64.cu:18)."""
+    z = 103
+    with orc.use_classes(classes):
+        d_ref = orc.dims(z)
+        g = L.geometry(z, classes)
+        d = L.dims(g)
+        assert (d.z, d.n_classes, d.nparams, d.off_w2, d.off_b2) == (z, classes, d_ref.nparams, d_ref.off_w2, d_ref.off_b2)
+        x, y = 21, 17
+        rng = np.random.default_rng(3)
+        labels = rng.integers(0, classes + 1, x * y).astype(np.float64)
+        di = prep.scan_labels(labels, x, y)
+        got = prep.build_index(labels, di, x, y, classes)
+        ref = orc.build_index(labels, orc.scan_labels(labels, x, y), x, y)
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b)
+        prep.shuffle(got[0], got[2], 11)
+        p32 = prep.init_params(g, np.float32)
+        orc.shuffle(ref[0], ref[2], 11)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[2], ref[2])
+        assert np.array_equal(p32, orc.init_params_f32(z))
+        orc.srand(5)
+        p64 = prep.init_params(g, np.float64, 7)
+        orc.srand(5)
+        assert np.array_equal(p64, orc.init_params_f64(z, 7))
+    # 13 classes reject a label of 14; the 16-class build takes it
+    labels[0] = 14
+    di = prep.scan_labels(labels, x, y)
+    if classes == 16:
+        with pytest.raises(L.CcnnError):
+            prep.build_index(labels, di, x, y)
+        prep.build_index(labels, di, x, y, 16)
+    with pytest.raises(L.CcnnError):
+        L.dims(L.geometry(z, 17))
