@@ -95,10 +95,11 @@ __host__ __device__ inline FusedLayout fused_layout(int re, int mre)
 // 2 filter tiles x 11 tap tiles, wave w of NW owns tap tiles w, w+NW, ..
 // delta is two position-major tiles [4 ks][16] (tile_len apart; filters 20..31 and positions
 // >= re zero) so that, like the forward filter tiles, A-fragment reads are bank-conflict free;
-// cube zero-padded; out = [F][K].
-template <typename T, int NW>
+// cube zero-padded; out = [F][K].  ONE: only the first delta tile exists and its columns are filters
+// fbase .. fbase + nf - 1 (a workgroup that owns half of the filters).
+template <typename T, int NW, bool ONE = false>
 __device__ __forceinline__ void conv_bwd_tiles(const T *cube, const T *delta, int tile_len, int ks, int re,
-                                               T *__restrict__ out, int lane, int wave)
+                                               T *__restrict__ out, int lane, int wave, int fbase = 0, int nf = F)
 {
     constexpr int NTT = (11 + NW - 1) / NW;   // tap tiles per wave: wave w owns w, w+NW, ..  (171 taps = 11 tiles)
     const int col = lane & 15, kq = lane >> 4;
@@ -120,7 +121,7 @@ __device__ __forceinline__ void conv_bwd_tiles(const T *cube, const T *delta, in
         for (int u = 0; u < 2; u++) {
             if (u < n) {
                 a0[u] = ap0[4 * (s + u) * LDWK];
-                a1[u] = ap1[4 * (s + u) * LDWK];
+                if (!ONE) a1[u] = ap1[4 * (s + u) * LDWK];
 #pragma unroll
                 for (int j = 0; j < NTT; j++) b[u][j] = bp[j][4 * (s + u) * WSTEP];
             }
@@ -132,7 +133,7 @@ __device__ __forceinline__ void conv_bwd_tiles(const T *cube, const T *delta, in
                 for (int j = 0; j < NTT; j++) {
                     if (live[j]) {
                         c0[j] = Mma<T>::mma(a0[u], b[u][j], c0[j]);
-                        c1[j] = Mma<T>::mma(a1[u], b[u][j], c1[j]);
+                        if (!ONE) c1[j] = Mma<T>::mma(a1[u], b[u][j], c1[j]);
                     }
                 }
             }
@@ -147,14 +148,14 @@ __device__ __forceinline__ void conv_bwd_tiles(const T *cube, const T *delta, in
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int f = ftile * 16 + Mma<T>::row(lane, r);
-            if (f < F) out[f * K + tap] = acc[r] / re;   // gcn_mbgd_fp64.cu:491
+            if (f < nf) out[(fbase + f) * K + tap] = acc[r] / re;   // gcn_mbgd_fp64.cu:491
         }
     };
 #pragma unroll
     for (int j = 0; j < NTT; j++) {
         if (live[j]) {
             emit(c0[j], 0, wave + j * NW);
-            emit(c1[j], 1, wave + j * NW);
+            if (!ONE) emit(c1[j], 1, wave + j * NW);
         }
     }
 }
@@ -166,7 +167,12 @@ __device__ __forceinline__ void conv_bwd_tiles(const T *cube, const T *delta, in
 // NO: the class count when it is the reference's 13 (a compile-time constant then: the head's
 // loops and its 13-wide tree cost what they cost before the count became a run-time property),
 // 0 for any other count (read from d).
-template <typename T, bool FLIP, int NT, int NO>
+// SPLIT = 2 (small batches, which leave half of the chip idle): two workgroups per sample, on one
+// XCD (blocks i and i + 8).  Both run the whole forward pass - splitting it would need a trade of
+// the FC1 partial sums between workgroups, which costs what it saves - and each takes the
+// backward pass of ten filters: its half of the second W1 walk, its filters' conv gradient.  No
+// workgroup waits for another, and every value is computed exactly as with one workgroup.
+template <typename T, bool FLIP, int NT, int NO, int SPLIT>
 __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ params,
                                                       const T *__restrict__ cubes,
                                                       const int *__restrict__ onehot, long first,
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ param
                                                       T *__restrict__ a1_g, T *__restrict__ d1_g,
                                                       T *__restrict__ d2_g, T *__restrict__ probs_g,
                                                       double *__restrict__ loss_values,
-                                                      T *__restrict__ slab)
+                                                      T *__restrict__ slab, int d_rows)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const FusedLayout L = fused_layout<T>(d.re, d.mre);
@@ -186,7 +192,10 @@ __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ param
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15;
     const int re = d.re, mre = d.mre, pout = d.pout, no = NO ? NO : d.n_classes;
-    const long row = blockIdx.x;
+    const int half = SPLIT == 2 ? (blockIdx.x >> 3) & 1 : 0;
+    const long row = SPLIT == 2 ? (blockIdx.x & 7) + 8 * (blockIdx.x >> 4) : blockIdx.x;
+    if (SPLIT == 2 && row >= d_rows) return;   // the grid is rounded up to whole groups of 8 samples
+    const bool lead = half == 0;               // the workgroup that stores the sample's shared outputs
     FB_TICK(0);
     int *lab = reinterpret_cast<int *>(smem + L.lab_off);
     // the labels are needed deep in the dependent chain: fetch them with the first loads
@@ -263,7 +272,8 @@ __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ param
 #if CCNN_STOP_PHASE == 2
     return;
 #endif
-    for (int o = tid; o < pout; o += NT) pool_g[row * pout + o] = pl[o];
+    if (lead)
+        for (int o = tid; o < pout; o += NT) pool_g[row * pout + o] = pl[o];
 
     // ---- FC1 forward: z1[n] = sum_p pool[p] W1[n + 100 p] ---------------------------
     // 16-byte vectors along n; QL lanes per W1 row (25 or 50 of them active), G row groups.
@@ -285,12 +295,12 @@ __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ param
     // Both walks visit the rows in the same order: (g + rot) mod pout, then steps of G (mod pout).
     // A running row number costs three instructions per row; rows past the end wrap onto valid
     // ones, so the loads stay unconditional without a clamp.
-    const unsigned p_first = (unsigned)((g + rot) % pout);
-    unsigned p_run = p_first;
+    unsigned wbase = 0, wlen = (unsigned)pout;   // the rows a walk covers: wbase + (0 .. wlen - 1)
+    unsigned p_run = (unsigned)((g + rot) % pout);
     auto next_row = [&]() {
         const unsigned p = p_run, t = p_run + G;
-        p_run = min(t, t - (unsigned)pout);   // t < pout: the difference wraps to a huge value
-        return p;
+        p_run = min(t, t - wlen);   // t < wlen: the difference wraps to a huge value
+        return wbase + p;
     };
     auto w1_rows = [&](V(&w)[UF]) {
 #pragma unroll
@@ -326,7 +336,7 @@ __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ param
         for (int gg = 0; gg < G; gg++) zsum = zsum + z1p[gg * H + tid];
         a = act(zsum + b1v);   // gcn_mbgd_fp64.cu:302
         a1s[tid] = a;
-        a1_g[row * H + tid] = a;
+        if (lead) a1_g[row * H + tid] = a;
     }
     __syncthreads();
 
@@ -349,10 +359,10 @@ __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ param
     if (tid < no) {
         const T p = es[tid] / tree_n(es, no);
         ps[tid] = p;
-        if (probs_g) probs_g[row * no + tid] = p;
+        if (probs_g && lead) probs_g[row * no + tid] = p;
         const T dv = (p - lab[tid]) / no;   // gcn_mbgd_fp64.cu:352
         d2s[tid] = dv;
-        d2_g[row * no + tid] = dv;
+        if (lead) d2_g[row * no + tid] = dv;
     }
     // the filters are dead: clear their region for the scattered deltas
     for (int e = tid; e < 2 * L.ldd; e += NT) wl[e] = 0;
@@ -365,7 +375,7 @@ __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ param
         for (int o = 0; o < OMAX; o++) prod[o] = w2b[o] * d2s[o];
         const T dv = tree_n(prod, no) * (1 + a) * (1 - a);
         d1s[tid] = dv;
-        d1_g[row * H + tid] = dv;
+        if (lead) d1_g[row * H + tid] = dv;
     }
     // the loss terms (a log and an exp each) are nobody's input: an idle wave computes them here
     if (tid >= NT - 64 && tid < NT - 64 + no) {
@@ -378,7 +388,7 @@ __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ param
     return;
 #endif
     // nothing waits for the loss: one thread adds its terms up while the walk below runs
-    if (tid == NT - 1) loss_values[row] = loss_sum(lta, ltb, lab, no);
+    if (tid == NT - 1 && lead) loss_values[row] = loss_sum(lta, ltb, lab, no);
 
     // ---- delta at the pooled features + bp_maxpooling scatter -----------------------
     // dpool[p] = (sum_n W1[n + 100 p] d1[n]) (1 + pool)(1 - pool), gcn_mbgd_fp64.cu:416-434, 450-452
@@ -389,6 +399,11 @@ __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ param
         static_assert(UF == 16, "reduce_scatter16 handles 16 rows per round");
         const int ru = reduce_scatter_index<QL>(q);          // the row of the round this lane ends up owning
         const bool writer = (q & (QL / 16 - 1)) == 0;        // one lane per owned row stores it
+        if (SPLIT == 2) {
+            wlen = (unsigned)(pout / 2);   // F is even: a half is ten whole filters
+            wbase = half * wlen;
+        }
+        const int wrot = rot % (int)wlen;
         auto dpool_rows = [&](int pb, const V(&w)[UF]) {
             T part[UF];   // d1v is zero in the lanes past the row's end
 #pragma unroll
@@ -399,18 +414,22 @@ __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ param
             }
             const T tot = reduce_scatter16<QL>(part, q);
             const int pi = pb + ru * G + g;
-            if (writer && pi < pout) {
-                int p = pi + rot;
-                p = p >= pout ? p - pout : p;
+            if (writer && pi < (int)wlen) {
+                int q = pi + wrot;
+                q = q >= (int)wlen ? q - (int)wlen : q;
+                const int p = (int)wbase + q;
                 const T pv = pl[p];
                 const T dv = tot * (1 + pv) * (1 - pv);
                 dp[p] = dv;
                 const int f = p / mre;
-                delta[(f >> 4) * L.ldd + px[p] * LDWK + (f & 15)] = dv;
+                if (SPLIT == 2)
+                    delta[px[p] * LDWK + (f - half * (F / 2))] = dv;   // own ten filters: columns 0..9 of the first tile
+                else
+                    delta[(f >> 4) * L.ldd + px[p] * LDWK + (f & 15)] = dv;
             }
         };
-        p_run = p_first;
-        for (int pb = 0; pb < pout; pb += CCNN_FB_UFB * G * UF) {
+        p_run = (unsigned)((g + wrot) % (int)wlen);
+        for (int pb = 0; pb < (int)wlen; pb += CCNN_FB_UFB * G * UF) {
             V w[CCNN_FB_UFB][UF];   // rows of several rounds in flight before the first is reduced
 #pragma unroll
             for (int h = 0; h < CCNN_FB_UFB; h++) w1_rows(w[h]);
@@ -426,17 +445,21 @@ __global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ param
 
     // ---- conv gradient tile of this sample -------------------------------------------
     T *out = slab + row * (long)(F * K + F);
-    conv_bwd_tiles<T, NW>(cube, wl, L.ldd, L.ks, re, out, lane, wave);
+    if (SPLIT == 2)
+        conv_bwd_tiles<T, NW, true>(cube, wl, L.ldd, L.ks, re, out, lane, wave, half * (F / 2), F / 2);
+    else
+        conv_bwd_tiles<T, NW>(cube, wl, L.ldd, L.ks, re, out, lane, wave);
     FB_TICK(9);
-    if (tid < F) {
+    if (tid < F / SPLIT) {
         // bias path: at a winner the conv output equals the pooled value, so the
         // reference's second tanh' (gcn_mbgd_fp64.cu:487-488) needs only pl
+        const int f = tid + half * (F / 2);
         T mid1 = 0;
         for (int m = 0; m < mre; m++) {
-            const T pv = pl[tid * mre + m];
-            mid1 = mid1 + dp[tid * mre + m] * (1 + pv) * (1 - pv);
+            const T pv = pl[f * mre + m];
+            mid1 = mid1 + dp[f * mre + m] * (1 + pv) * (1 - pv);
         }
-        out[F * K + tid] = mid1 / re;
+        out[F * K + f] = mid1 / re;
     }
     FB_TICK(10);
 }
@@ -960,6 +983,20 @@ inline bool use_batched(int B)
     }
     return B >= BATCHED_MIN_B;
 }
+// Two workgroups per sample in the fused kernel: while both halves of every sample fit the device
+// at once, one workgroup per CU (CCNN_FB_SPLIT=0|1 overrides: diagnostics and tests).
+inline bool split_samples(int B)
+{
+    static const int forced = [] {
+        const char *s = getenv("CCNN_FB_SPLIT");
+        return s ? atoi(s) : -1;
+    }();
+    if (forced >= 0) return forced != 0;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return false;
+    return 16 * ((B + 7) / 8) <= cus;
+}
 inline int batched_splits(int B)
 {
     const int s = (B + BATCHED_SPLIT_ROWS - 1) / BATCHED_SPLIT_ROWS;
@@ -1133,12 +1170,15 @@ int mbgd_impl(const T *params, const T *cubes, const int *onehot, long first, in
     MbgdWs<T> w(ws, B, d);
     if (use_batched(B)) return mbgd_batched<T, FLIP>(params, cubes, onehot, first, B, z, d, grad, upd, loss_values, probs, w, st, cm);
     const FusedLayout L = fused_layout<T>(d.re, d.mre);
-    const auto fb = d.n_classes == CCNN_CLASSES ? sample_fwd_bwd<T, FLIP, FB_THREADS, CCNN_CLASSES>
-                                                : sample_fwd_bwd<T, FLIP, FB_THREADS, 0>;
+    // two workgroups per sample while that still fits the chip in one round (one workgroup per CU)
+    const bool split = split_samples(B);
+    const bool c13 = d.n_classes == CCNN_CLASSES;
+    const auto fb = split ? (c13 ? sample_fwd_bwd<T, FLIP, FB_THREADS, CCNN_CLASSES, 2> : sample_fwd_bwd<T, FLIP, FB_THREADS, 0, 2>)
+                          : (c13 ? sample_fwd_bwd<T, FLIP, FB_THREADS, CCNN_CLASSES, 1> : sample_fwd_bwd<T, FLIP, FB_THREADS, 0, 1>);
     if (int e = allow_smem(fb, L.bytes)) return e;
     {
-        launch("sample_fwd_bwd", fb, dim3(B), dim3(FB_THREADS), L.bytes, st, params, cubes, onehot, first,
-               d, w.pool, w.a1, w.d1, w.d2, probs, loss_values, w.slab);
+        launch("sample_fwd_bwd", fb, dim3(split ? 16 * ((B + 7) / 8) : B), dim3(FB_THREADS), L.bytes, st, params, cubes,
+               onehot, first, d, w.pool, w.a1, w.d1, w.d2, probs, loss_values, w.slab, B);
     }
     CCNN_LAUNCH_CHECK();
     return launch_grad_reduce<T>(B, d, w, B, 1, grad, 0, upd, cm, st);
