@@ -172,8 +172,11 @@ __device__ __forceinline__ void conv_bwd_tiles(const T *cube, const T *delta, in
 // the FC1 partial sums between workgroups, which costs what it saves - and each takes the
 // backward pass of ten filters: its half of the second W1 walk, its filters' conv gradient.  No
 // workgroup waits for another, and every value is computed exactly as with one workgroup.
-template <typename T, bool FLIP, int NT, int NO, int SPLIT>
-__global__ __launch_bounds__(NT) void sample_fwd_bwd(const T *__restrict__ params,
+// WPE: waves per SIMD the register allocation must leave room for (2: one workgroup per CU, all
+// the registers the chain wants; 4: two workgroups per CU, for batches of more samples than CUs,
+// whose second round then runs beside the first instead of after it).
+template <typename T, bool FLIP, int NT, int NO, int SPLIT, int WPE = 2>
+__global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ params,
                                                       const T *__restrict__ cubes,
                                                       const int *__restrict__ onehot, long first,
                                                       ccnn_dims_t d, T *__restrict__ pool_g,
@@ -985,6 +988,13 @@ inline bool use_batched(int B)
 }
 // Two workgroups per sample in the fused kernel: while both halves of every sample fit the device
 // at once, one workgroup per CU (CCNN_FB_SPLIT=0|1 overrides: diagnostics and tests).
+inline int fb_cus()
+{
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return 0;
+    return cus;
+}
 inline bool split_samples(int B)
 {
     static const int forced = [] {
@@ -1173,8 +1183,11 @@ int mbgd_impl(const T *params, const T *cubes, const int *onehot, long first, in
     // two workgroups per sample while that still fits the chip in one round (one workgroup per CU)
     const bool split = split_samples(B);
     const bool c13 = d.n_classes == CCNN_CLASSES;
-    const auto fb = split ? (c13 ? sample_fwd_bwd<T, FLIP, FB_THREADS, CCNN_CLASSES, 2> : sample_fwd_bwd<T, FLIP, FB_THREADS, 0, 2>)
-                          : (c13 ? sample_fwd_bwd<T, FLIP, FB_THREADS, CCNN_CLASSES, 1> : sample_fwd_bwd<T, FLIP, FB_THREADS, 0, 1>);
+    static const int dense_env = getenv("CCNN_FB_DENSE") ? atoi(getenv("CCNN_FB_DENSE")) : -1;   // diagnostics
+    const bool dense = dense_env >= 0 ? dense_env != 0 : (!split && sizeof(T) == 4 && B > fb_cus());
+    const auto fb = split   ? (c13 ? sample_fwd_bwd<T, FLIP, FB_THREADS, CCNN_CLASSES, 2> : sample_fwd_bwd<T, FLIP, FB_THREADS, 0, 2>)
+                    : dense ? (c13 ? sample_fwd_bwd<T, FLIP, FB_THREADS, CCNN_CLASSES, 1, 4> : sample_fwd_bwd<T, FLIP, FB_THREADS, 0, 1, 4>)
+                            : (c13 ? sample_fwd_bwd<T, FLIP, FB_THREADS, CCNN_CLASSES, 1> : sample_fwd_bwd<T, FLIP, FB_THREADS, 0, 1>);
     if (int e = allow_smem(fb, L.bytes)) return e;
     {
         launch("sample_fwd_bwd", fb, dim3(split ? 16 * ((B + 7) / 8) : B), dim3(FB_THREADS), L.bytes, st, params, cubes,
