@@ -534,7 +534,7 @@ __device__ __forceinline__ T colsum8(int B, int rg, int c, T *red, Term term)
 // workgroup only depends on its namesakes on the other ranks.
 //
 // gridDim.y > 1 (large batches): split y sums only rows [y Bs, (y+1) Bs) of the batch (and of the
-// conv-gradient slab, whose row count need not be B) and stores its sums in grad + y * grad_stride;
+// conv-gradient slab's few rows all go to split 0) and stores its sums in grad + y * grad_stride;
 // apply_partials then adds the splits in order.  A single 2048-row sum per thread would be 16
 // dependent rounds of loads.
 template <typename T, int KF, int NO>
@@ -561,9 +561,9 @@ __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int o
         d1 += (long)b_lo * H;
         d2 += (long)b_lo * no;
         B = min(bs, B - b_lo);
-        const int ss = (slab_rows + ny - 1) / ny, s_lo = min(y * ss, slab_rows);
-        slab_rows = min(ss, slab_rows - s_lo);
-        if (slab_rows > 0) slab += (long)s_lo * (F * K + F);   // an empty share keeps pointing at row 0 (loads are clamped, unmasked values unused)
+        // the conv-gradient rows are few (one per workgroup of conv_bwd_batch): split 0 sums them
+        // all and the other splits' workgroups for those columns have nothing to do
+        if (y > 0 && blk >= nb_w1 && blk < nb_w1 + nb_w0) return;
         grad += y * grad_stride;
     }
     int ok[4] = {-1, -1, -1, -1};   // parameter index of this thread's outputs (-1: none)
@@ -957,14 +957,16 @@ __global__ __launch_bounds__(CB_THREADS) void conv_bwd_batch(const T *__restrict
 }
 
 // w -= lr * (sum over the S batch splits, in order) [/ divisor], or grad = that sum.
+// Entries below single_hi (the conv weights and bias) have one partial only: split 0's.
 template <typename T>
-__global__ void apply_partials(const T *__restrict__ part, int S, long stride, int n, T *__restrict__ grad,
+__global__ void apply_partials(const T *__restrict__ part, int S, long stride, int n, int single_hi, T *__restrict__ grad,
                                UpdateRule<T> upd)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     T tot = 0;
-    for (int s = 0; s < S; s++) tot = tot + part[s * stride + k];
+    const int ns = k < single_hi ? 1 : S;
+    for (int s = 0; s < ns; s++) tot = tot + part[s * stride + k];
     upd.apply(grad, k, tot);
 }
 
@@ -1157,7 +1159,7 @@ int mbgd_batched(const T *params, const T *cubes, const int *onehot, long first,
     T *out = cm ? w.gsum : grad;
     UpdateRule<T> rule = cm ? UpdateRule<T>{} : upd;
     launch("apply_partials", apply_partials<T>, dim3((d.nparams + 255) / 256), dim3(256), 0, st, (const T *)w.parts, S,
-           (long)d.nparams, d.nparams, out, rule);
+           (long)d.nparams, d.nparams, d.off_w1, out, rule);
     CCNN_LAUNCH_CHECK();
     if (cm) {
         if (!upd.params) return CCNN_E_INVALID;
