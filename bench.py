@@ -381,9 +381,17 @@ def main():
                 print(f"one-shot exchange unavailable ({e}); using RCCL", file=sys.stderr)
             comm = None
 
-    # route of the N>1 step: "instep" (exchange inside the reduction kernel), "standalone" (gradient,
-    # then the library's exchange + update kernel) or "rccl" (gradient, RCCL all-reduce, update)
-    mode = "instep" if comm is not None else "rccl"
+    # route of the N>1 step: "instep" (exchange inside the reduction kernel, every rank writing to
+    # every rank), "instep_owner" (the same with the sums meeting at an owner rank that sends the total
+    # round: fewer bytes per link, one more hop), "standalone" (gradient, then the library's exchange +
+    # update kernel) or "rccl" (gradient, RCCL all-reduce, update)
+    mode = ("instep_owner" if world >= 4 else "instep") if comm is not None else "rccl"
+
+    def set_mode(m):
+        nonlocal mode
+        mode = m
+        if comm is not None and m.startswith("instep"):
+            comm.set_exchange(m == "instep_owner")
     log(f"exchange set up: mode {mode}" + (f", ranks share a device: {comm.shared_device}" if comm is not None else ""))
 
     def step(i):
@@ -391,7 +399,7 @@ def main():
         if not use_dist:
             # gradient + update fused (nothing has to happen in between on one GPU)
             ops.mbgd_step(params, cubes, onehot_d, b * B, B, z, lr, loss_values=loss_ring[b], workspace=ws)
-        elif mode == "instep":
+        elif mode in ("instep", "instep_owner"):
             # two launches: the reduction kernel trades its sums with the other ranks and updates
             ops.mbgd_step(params, cubes, onehot_d, b * B, B, z, lr, loss_values=loss_ring[b], workspace=ws, comm=comm)
         else:
@@ -465,8 +473,8 @@ def main():
         elif os.environ.get("CCNN_ALLREDUCE", "") != "oneshot":
             ncal = max(args.warmup, 50)
             times = {}
-            for m in ("instep", "standalone", "rccl"):
-                mode = m
+            for m in ("instep", "instep_owner", "standalone", "rccl"):
+                set_mode(m)
                 for i in range(3):
                     step(i)
                 if m != "rccl" and stalled():            # a wait timed out: not a candidate, and not worth 200 more waits
@@ -479,7 +487,7 @@ def main():
                     times[m] = float("inf")
             calibration = {"steps": ncal, **{f"{m}_us_per_step": (round(t / ncal * 1e6, 2) if t != float("inf") else None)
                                              for m, t in times.items()}}
-            mode = min(times, key=times.get)
+            set_mode(min(times, key=times.get))
         if mode == "rccl":
             comm.close()
             comm = None
@@ -680,6 +688,7 @@ def main():
                        "global_batch": B * world, "train_pixels": T, "parallelism": f"dp{world}",
                        "exchange": ("none" if not use_dist else
                                     {"instep": "xgmi one-shot exchange inside the reduction kernel",
+                                     "instep_owner": "xgmi exchange inside the reduction kernel, sums reduced at an owner rank and sent round",
                                      "standalone": "xgmi one-shot exchange + update kernel after the gradient",
                                      "rccl": "rccl all-reduce + update"}[mode]),
                        "exchange_calibration": calibration, "replicas_identical": replicas_identical,

@@ -66,6 +66,12 @@ class NodeComm:
             dist.barrier(group=self.group)   # nobody recycles its buffer while a peer still maps it
             self._destroy()
 
+    def set_exchange(self, via_owner):
+        """How the in-step exchange moves its sums (ccnn_comm_set_exchange): False = every rank
+        writes to every rank, True = reduce at an owner rank that sends the total round.  Same
+        results; every rank must make the same call."""
+        _l.check(_l.load().ccnn_comm_set_exchange(self._h, int(bool(via_owner))), "ccnn_comm_set_exchange")
+
     def status(self):
         st = C.c_int(0)
         _l.check(_l.load().ccnn_comm_status(self._h, C.byref(st)), "ccnn_comm_status")

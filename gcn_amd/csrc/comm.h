@@ -28,6 +28,7 @@ struct CommDev {            // passed to kernels by value; world == 0 means "no 
     long flags_off, status_off;   // byte offsets inside a buffer (the word after status holds the rank's nonce)
     int nflags;
     unsigned long long spin_ticks;   // how long a workgroup waits for a peer (100 MHz ticks)
+    int via_owner;                // in-step exchange: 0 = every rank writes to every rank; 1 = reduce at an owner, who sends the sum round
 };
 
 #ifdef __HIPCC__

@@ -20,6 +20,9 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
+#include <vector>
+#include <cstring>
 #include <new>
 #include <random>
 
@@ -148,6 +151,51 @@ void log_handle(const char *what, int rank, int peer, const void *ptr, const voi
     fprintf(stderr, "[ccnn-comm rank %d] %s peer=%d ptr=%p rc=%d handle=%s\n", rank, what, peer, ptr, rc, hex);
 }
 
+// Exchange buffers live as long as the process: ccnn_comm_destroy hands a buffer back to this
+// list and a later ccnn_comm_create on the same device takes it again (zeroed).  Memory that peer
+// PROCESSES have had mapped is not safe to give back to the allocator while they are alive:
+// measured with two ranks on one GPU (tools/owner_debug2.py), after hipFree of a first set of
+// buffers the next large allocation of the owner - a training workspace - produced gradients that
+// were wrong by up to 20 % and changed from call to call, with the inputs intact and no wait timed
+// out, in 8 of 12 runs; 0 of 6 with the buffers kept, 0 of 6 with the workspace allocated before
+// the first set existed.  Every close and free had returned success and every set had its own
+// addresses and handles, so what still reaches the freed pages was not identified; not freeing
+// them avoids the question.
+struct PooledBuffer {
+    void *ptr;
+    size_t bytes;
+    int device;
+    bool in_use;
+};
+std::mutex g_pool_mu;
+std::vector<PooledBuffer> g_pool;
+
+hipError_t pool_acquire(int device, size_t bytes, void **out)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (PooledBuffer &b : g_pool) {
+        if (!b.in_use && b.device == device && b.bytes >= bytes) {
+            b.in_use = true;
+            *out = b.ptr;
+            return hipSuccess;
+        }
+    }
+    void *p = nullptr;
+    // uncached: peers write it over xGMI behind the local L2's back
+    const hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) return e;
+    g_pool.push_back({p, bytes, device, true});
+    *out = p;
+    return hipSuccess;
+}
+
+void pool_release(void *ptr)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (PooledBuffer &b : g_pool)
+        if (b.ptr == ptr) b.in_use = false;
+}
+
 }  // namespace
 
 extern "C" {
@@ -167,6 +215,15 @@ int ccnn_comm_create(int world, int rank, long max_elems, int elem_size, ccnn_co
     d.world = world;
     d.rank = rank;
     d.spin_ticks = COMM_SPIN_TICKS;
+    // In-step exchange: with four or more ranks a workgroup's sums go to one owner rank, who adds
+    // them and sends the total round - a quarter (8 ranks) of the bytes per link of everybody
+    // writing to everybody, for one more hop.  CCNN_COMM_EXCHANGE=direct|owner overrides;
+    // ccnn_comm_set_exchange changes it later.
+    d.via_owner = world >= 4;
+    if (const char *ex = getenv("CCNN_COMM_EXCHANGE")) {
+        if (!strcmp(ex, "direct")) d.via_owner = 0;
+        if (!strcmp(ex, "owner")) d.via_owner = 1;
+    }
     if (const char *ms = getenv("CCNN_COMM_WAIT_MS")) {   // tests shorten the limit
         const long v = atol(ms);
         if (v > 0) d.spin_ticks = (unsigned long long)v * 100000ull;
@@ -187,8 +244,7 @@ int ccnn_comm_create(int world, int rank, long max_elems, int elem_size, ccnn_co
     hipError_t e = hipGetDevice(&cm->device);
     void *buf = nullptr;
     cm->shared_device = cm->any_shared = false;
-    // uncached: peers write it over xGMI behind the local L2's back
-    if (e == hipSuccess) e = hipExtMallocWithFlags(&buf, cm->total_bytes, hipDeviceMallocUncached);
+    if (e == hipSuccess) e = pool_acquire(cm->device, cm->total_bytes, &buf);
     if (e == hipSuccess) e = hipMemset(buf, 0, cm->total_bytes);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) {
@@ -204,7 +260,7 @@ int ccnn_comm_create(int world, int rank, long max_elems, int elem_size, ccnn_co
     if (e == hipSuccess) e = hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t *>(handle), buf);
     log_handle("create", rank, rank, buf, handle, (int)e);
     if (e != hipSuccess) {
-        if (buf) (void)hipFree(buf);
+        if (buf) pool_release(buf);
         delete cm;
         return (int)e;
     }
@@ -279,6 +335,13 @@ int ccnn_comm_shares_device(ccnn_comm_t *cm, int *shared)
     return 0;
 }
 
+int ccnn_comm_set_exchange(ccnn_comm_t *cm, int via_owner)
+{
+    if (!cm || (via_owner != 0 && via_owner != 1)) return CCNN_E_INVALID;
+    cm->dev.via_owner = via_owner;
+    return 0;
+}
+
 int ccnn_comm_status(ccnn_comm_t *cm, int *status)
 {
     if (!cm || !status) return CCNN_E_INVALID;
@@ -310,14 +373,12 @@ int ccnn_comm_destroy(ccnn_comm_t *cm)
 {
     if (!cm) return 0;
     const int rc = ccnn_comm_disconnect(cm);
-    int rc_free = 0;
     if (cm->dev.peer[cm->dev.rank]) {
-        const hipError_t e = hipFree(cm->dev.peer[cm->dev.rank]);
-        log_handle("free", cm->dev.rank, cm->dev.rank, cm->dev.peer[cm->dev.rank], nullptr, (int)e);
-        rc_free = (int)e;
+        log_handle("keep", cm->dev.rank, cm->dev.rank, cm->dev.peer[cm->dev.rank], nullptr, 0);
+        pool_release(cm->dev.peer[cm->dev.rank]);   // kept for the next comm of this process, never freed
     }
     delete cm;
-    return rc ? rc : rc_free;
+    return rc;
 }
 
 int ccnn_allreduce_f32(ccnn_comm_t *cm, float *buf, long n, void *stream)

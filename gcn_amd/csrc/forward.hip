@@ -880,3 +880,24 @@ int ccnn_update_adagrad_f64(double *params, double *rms, const double *grad, dou
 }
 
 }  // extern "C"
+
+#ifdef CCNN_DEBUG_LDS_POISON
+// Diagnostic builds only: fills the LDS of every CU with 0xFF bytes (NaN as floats), so that a
+// kernel which reads LDS it never wrote shows up as a changed result.
+__global__ void poison_lds_kernel(int words)
+{
+    extern __shared__ unsigned lds_words[];
+    for (int i = threadIdx.x; i < words; i += blockDim.x) lds_words[i] = 0xffffffffu;
+    __syncthreads();
+    if (lds_words[(threadIdx.x * 7919) % words] != 0xffffffffu) __builtin_trap();
+}
+extern "C" int ccnn_debug_poison_lds(void *stream)
+{
+    const size_t bytes = 160 * 1024;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(poison_lds_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(poison_lds_kernel, dim3(1024), dim3(256), bytes, (hipStream_t)stream, (int)(bytes / 4));
+    return (int)hipGetLastError();
+}
+#endif

@@ -666,32 +666,70 @@ __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int o
                     bits[2 * j + 1] = (unsigned)(q >> 32);
                 }
             }
-            for (int k = 0; k < xc.world; k++) {
-                const int r = (xc.rank + 1 + k) % xc.world;   // start at the next rank: spreads the writes over the links
-                unsigned long long *dst = reinterpret_cast<unsigned long long *>(comm_slot(xc, r, par, xc.rank)) + word0;
+            auto send = [&](int to, int slot_of, const unsigned *b) {   // this thread's words into `to`'s buffer, slot [par][slot_of]
+                unsigned long long *dst = reinterpret_cast<unsigned long long *>(comm_slot(xc, to, par, slot_of)) + word0;
 #pragma unroll
-                for (int h = 0; h < WPV; h++) comm_store_tagged(dst + 4 * h, bits + 4 * h, max(min(nv * WPV - 4 * h, 4), 0), xstep);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) og[j] = 0;
-            for (int r = 0; r < xc.world; r++) {   // rank order: the same bits on every rank
+                for (int h = 0; h < WPV; h++) comm_store_tagged(dst + 4 * h, b + 4 * h, max(min(nv * WPV - 4 * h, 4), 0), xstep);
+            };
+            auto receive = [&](int slot_of, unsigned *in) {              // from the local buffer, slot [par][slot_of]
                 const unsigned long long *src =
-                    reinterpret_cast<const unsigned long long *>(comm_slot(xc, xc.rank, par, r)) + word0;
-                unsigned in[4 * WPV];
+                    reinterpret_cast<const unsigned long long *>(comm_slot(xc, xc.rank, par, slot_of)) + word0;
 #pragma unroll
                 for (int h = 0; h < WPV; h++)
                     if (!comm_load_tagged(src + 4 * h, in + 4 * h, max(min(nv * WPV - 4 * h, 4), 0), xstep, xc)) gave_up = 1;
-                if (gave_up) break;   // in[] is not set: nothing of this step may reach the parameters
+            };
+            auto value = [&](const unsigned *in, int j) -> T {
+                if (WPV == 1) return (T)__uint_as_float(in[j]);
+                const unsigned long long q = (unsigned long long)in[2 * j] | ((unsigned long long)in[2 * j + 1] << 32);
+                return (T)__longlong_as_double((long long)q);
+            };
+            // via_owner: the workgroup's sums of all ranks meet at ONE rank (workgroup b: rank b mod
+            // world), which adds them in rank order and sends the total to everybody: 2 (world-1)/world
+            // of a vector per rank over the links instead of world-1 vectors, for a second hop.  A
+            // workgroup's slots [par][r] are used in one direction only per call (contributions at the
+            // owner, the total elsewhere), so both hops share the buffers and the sequence number.
+            const int owner = xc.via_owner ? (int)(blockIdx.x % xc.world) : -1;
+            unsigned in[4 * WPV];
+            if (owner >= 0 && owner != xc.rank) {
+                send(owner, xc.rank, bits);
+                receive(owner, in);
+                if (!gave_up) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (j < nv) og[j] = value(in, j);
+                }
+            } else {
+                if (owner < 0) {
+                    for (int k = 0; k < xc.world; k++)
+                        send((xc.rank + 1 + k) % xc.world, xc.rank, bits);   // start at the next rank: spreads the writes over the links
+                }
+                T mine[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    if (j < nv) {
+                    mine[j] = og[j];
+                    og[j] = 0;
+                }
+                for (int r = 0; r < xc.world; r++) {   // rank order: the same bits on every rank
+                    const bool own = owner >= 0 && r == xc.rank;   // the owner's own sums never leave its registers
+                    if (!own) receive(r, in);
+                    if (gave_up) break;   // in[] is not set: nothing of this step may reach the parameters
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (j < nv) og[j] = og[j] + (own ? mine[j] : value(in, j));
+                }
+                if (owner >= 0 && !gave_up) {
+                    unsigned tot[4 * WPV];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
                         if (WPV == 1) {
-                            og[j] = og[j] + (T)__uint_as_float(in[j]);
+                            tot[j] = __float_as_uint((float)og[j]);
                         } else {
-                            const unsigned long long q = (unsigned long long)in[2 * j] | ((unsigned long long)in[2 * j + 1] << 32);
-                            og[j] = og[j] + (T)__longlong_as_double((long long)q);
+                            const unsigned long long q = (unsigned long long)__double_as_longlong((double)og[j]);
+                            tot[2 * j] = (unsigned)q;
+                            tot[2 * j + 1] = (unsigned)(q >> 32);
                         }
                     }
+                    for (int k = 0; k + 1 < xc.world; k++) send((xc.rank + 1 + k) % xc.world, xc.rank, tot);
                 }
             }
         }

@@ -74,6 +74,7 @@ _SIG = {
     "ccnn_comm_connect_local": (C.c_int, [_P, C.POINTER(_P)]),
     "ccnn_comm_status": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "ccnn_comm_shares_device": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "ccnn_comm_set_exchange": (C.c_int, [_P, C.c_int]),
     "ccnn_comm_disconnect": (C.c_int, [_P]),
     "ccnn_comm_destroy": (C.c_int, [_P]),
     "ccnn_allreduce_f32": (C.c_int, [_P, _P, C.c_long, _P]),

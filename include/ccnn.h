@@ -323,10 +323,20 @@ int ccnn_comm_status(ccnn_comm_t *comm, int *status);
  * launches close together or use ccnn_mbgd_grad_* + ccnn_allreduce_update_* (whose waiting
  * kernel leaves room for the peers' work).  No counterpart in the reference. */
 int ccnn_comm_shares_device(ccnn_comm_t *comm, int *shared);
+/* How ccnn_mbgd_step_dp_* trades its sums: via_owner = 0, every rank writes each workgroup's
+ * sums to every rank (one hop, world-1 vectors per rank over the links); via_owner = 1, they meet
+ * at one owner rank per workgroup, which adds them and sends the total round (two hops,
+ * 2 (world-1)/world of a vector per rank).  The sums are added in rank order either way: the
+ * results are bit-identical.  Default: 1 from four ranks up (CCNN_COMM_EXCHANGE=direct|owner
+ * overrides at creation).  Every rank must use the same setting for the same call.  No
+ * counterpart in the reference. */
+int ccnn_comm_set_exchange(ccnn_comm_t *comm, int via_owner);
 /* Tear-down is two-phase across ranks: every rank first unmaps its peers' buffers
  * (ccnn_comm_disconnect; returns the first unmap error, if any), and only when ALL ranks
- * have done so may any rank free its own (ccnn_comm_destroy; it disconnects first if that
- * was not done). */
+ * have done so may any rank destroy its own comm (ccnn_comm_destroy; it disconnects first if
+ * that was not done).  The exchange buffer itself is not given back to the allocator: the
+ * library keeps it for the process's next ccnn_comm_create on that device (memory that other
+ * processes have had mapped proved unsafe to reuse for anything else while they live). */
 int ccnn_comm_disconnect(ccnn_comm_t *comm);
 int ccnn_comm_destroy(ccnn_comm_t *comm);
 /* buf[k] = sum over ranks of buf[k], in place. */

@@ -120,6 +120,13 @@ def main():
         # training run does with fresh buffers) and at two batch sizes
         assert comm._self_test_step(z), "first in-step exchange on fresh buffers"
         assert comm._self_test_step(z, B=12)
+        # both forms of the in-step exchange, whatever the default for this many ranks is:
+        # everybody writes to everybody / reduce at an owner rank that sends the total round
+        for via_owner in (True, False, True):
+            comm.set_exchange(via_owner)
+            assert comm._self_test_step(z, B=9), f"in-step exchange, via_owner={via_owner}"
+            assert comm._self_test_step(z, B=16), f"in-step exchange, via_owner={via_owner}"
+        comm.set_exchange(world >= 4)
         assert comm.self_test(z=z)
         # short vector (one partial chunk) and repeated calls (slot parity, sequence numbers)
         for n in (1, 5, 1023, 1025):
