@@ -107,9 +107,27 @@ def main():
         return
     z = 103
     d = L.dims(z)
-    # three sets of exchange buffers in a row: each set is freed and the next allocated afresh
-    # (possibly over the same memory), so sequence numbers and stale contents are covered
-    for dtype in (torch.float64, torch.float32, torch.float64):
+
+    # A local fp64 gradient whose workspace is above 1 MB (the allocator's large blocks), computed
+    # before any exchange buffer exists and again after every set has been given up: memory that
+    # peers have had mapped must never come back as somebody's workspace (it did, when destroy
+    # freed the buffers: gradients off by up to 20 %).
+    def local_gradient():
+        import numpy as np
+        from gcn_amd import ops
+        rng = np.random.default_rng(5)
+        p = torch.from_numpy((rng.random(d.nparams) - 0.5) / 10).to(dev)
+        cubes = torch.from_numpy(rng.random((40, d.cube))).to(dev)
+        oh = np.zeros((40, 13), dtype=np.int32)
+        oh[np.arange(40), rng.integers(0, 13, 40)] = 1
+        g, lv = ops.mbgd_grad(p, cubes, torch.from_numpy(oh).to(dev), 0, 40, z)
+        torch.cuda.synchronize()
+        return g.clone(), lv.clone()
+
+    g_first, lv_first = local_gradient()
+    # three sets of exchange buffers in a row: each set is given up and the next created afresh
+    # (over the same memory), so sequence numbers and stale contents are covered
+    for dtype in (torch.float32, torch.float64, torch.float32):
         comm = NodeComm(d.nparams, dtype)
         a = torch.ones(8, dtype=dtype, device=dev)
         comm.all_reduce(a)
@@ -179,6 +197,9 @@ def main():
         assert all(torch.equal(every[0], e) for e in every)
         assert comm.status() == 0
         comm.close()
+        for _ in range(3):
+            g, lv = local_gradient()
+            assert torch.equal(g, g_first) and torch.equal(lv, lv_first), "a local gradient changed after an exchange set was given up"
     if rank == 0:
         print("COMM-OK", world, flush=True)
     dist.destroy_process_group()
