@@ -1028,11 +1028,22 @@ inline bool use_batched(int B)
 }
 // Two workgroups per sample in the fused kernel: while both halves of every sample fit the device
 // at once, one workgroup per CU (CCNN_FB_SPLIT=0|1 overrides: diagnostics and tests).
-inline int fb_cus()
+inline int fb_cus()   // compute units of the current device (looked up once per device)
 {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-        return 0;
+    static std::mutex mu;
+    static int known[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (dev >= 0 && dev < 64) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (known[dev] > 0) return known[dev];
+    }
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (dev >= 0 && dev < 64) {
+        std::lock_guard<std::mutex> lk(mu);
+        known[dev] = cus;
+    }
     return cus;
 }
 inline bool split_samples(int B)
@@ -1042,10 +1053,7 @@ inline bool split_samples(int B)
         return s ? atoi(s) : -1;
     }();
     if (forced >= 0) return forced != 0;
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-        return false;
-    return 16 * ((B + 7) / 8) <= cus;
+    return 16 * ((B + 7) / 8) <= fb_cus();
 }
 inline int batched_splits(int B)
 {

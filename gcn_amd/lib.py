@@ -125,9 +125,16 @@ def check(code, what):
         raise CcnnError(code, what)
 
 
+_DIMS = {}
+
+
 def dims(z):
-    d = Dims()
-    check(load().ccnn_get_dims(int(z), C.byref(d)), "ccnn_get_dims")
+    """ccnn_get_dims, remembered per geometry (every op asks on every call)."""
+    d = _DIMS.get(z)
+    if d is None:
+        d = Dims()
+        check(load().ccnn_get_dims(int(z), C.byref(d)), "ccnn_get_dims")
+        _DIMS[z] = d
     return d
 
 

@@ -42,6 +42,18 @@ def _sfx(dtype):
     raise TypeError(f"unsupported dtype {dtype}")
 
 
+_WS_BYTES = {}
+
+
+def _mbgd_ws_bytes(lib, B, z, es):
+    """ccnn_mbgd_workspace_bytes, remembered (the training loop asks on every step)."""
+    k = (B, z, es)
+    n = _WS_BYTES.get(k)
+    if n is None:
+        n = _WS_BYTES[k] = lib.ccnn_mbgd_workspace_bytes(B, z, es)
+    return n
+
+
 class Workspace:
     """A reusable device scratch buffer (grown on demand, never shrunk)."""
 
@@ -207,7 +219,7 @@ def mbgd_grad(params, cubes, onehot, first, B, z, grad=None, loss_values=None, p
     if probs is not None:
         _req(probs, params.dtype, "probs", B * d.n_classes)
     lib = _l.load()
-    ws = (workspace or Workspace(params.device)).get(lib.ccnn_mbgd_workspace_bytes(B, z, es))
+    ws = (workspace or Workspace(params.device)).get(_mbgd_ws_bytes(lib, B, z, es))
     fn = getattr(lib, f"ccnn_mbgd_grad_{sfx}")
     _l.check(fn(_ptr(params), _ptr(cubes), _ptr(onehot), first, B, z, _ptr(grad), _ptr(loss_values), _ptr(probs),
                 _ptr(ws), ws.numel(), _stream()), f"ccnn_mbgd_grad_{sfx}")
@@ -233,7 +245,7 @@ def mbgd_step(params, cubes, onehot, first, B, z, lr, loss_values=None, workspac
     if loss_values.numel() < B:
         raise ValueError("loss_values shorter than the batch")
     lib = _l.load()
-    ws = (workspace or Workspace(params.device)).get(lib.ccnn_mbgd_workspace_bytes(B, z, es))
+    ws = (workspace or Workspace(params.device)).get(_mbgd_ws_bytes(lib, B, z, es))
     if comm is not None:
         fn = getattr(lib, f"ccnn_mbgd_step_dp_{sfx}")
         extra = () if params.dtype == torch.float32 else (int(divisor if divisor else B * comm.world),)
