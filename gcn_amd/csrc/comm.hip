@@ -154,7 +154,7 @@ void log_handle(const char *what, int rank, int peer, const void *ptr, const voi
 // Exchange buffers live as long as the process: ccnn_comm_destroy hands a buffer back to this
 // list and a later ccnn_comm_create on the same device takes it again (zeroed).  Memory that peer
 // PROCESSES have had mapped is not safe to give back to the allocator while they are alive:
-// measured with two ranks on one GPU (tools/owner_debug2.py), after hipFree of a first set of
+// measured with two ranks on one GPU (tools/comm_reuse_probe.py), after hipFree of a first set of
 // buffers the next large allocation of the owner - a training workspace - produced gradients that
 // were wrong by up to 20 % and changed from call to call, with the inputs intact and no wait timed
 // out, in 8 of 12 runs; 0 of 6 with the buffers kept, 0 of 6 with the workspace allocated before
