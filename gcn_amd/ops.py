@@ -6,6 +6,7 @@ work on torch's current stream.  Names follow the reference's kernel groups:
 gather (preprocessing), forward (the test loop), sgd, mbgd_grad, update.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -46,8 +47,9 @@ _WS_BYTES = {}
 
 
 def _mbgd_ws_bytes(lib, B, z, es):
-    """ccnn_mbgd_workspace_bytes, remembered (the training loop asks on every step)."""
-    k = (B, z, es)
+    """ccnn_mbgd_workspace_bytes, remembered (the training loop asks on every step).  The size depends
+    on which implementation of the step the library picks, and CCNN_MBGD_PATH can override that."""
+    k = (B, z, es, os.environ.get("CCNN_MBGD_PATH"))
     n = _WS_BYTES.get(k)
     if n is None:
         n = _WS_BYTES[k] = lib.ccnn_mbgd_workspace_bytes(B, z, es)
