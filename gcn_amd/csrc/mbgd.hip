@@ -1015,16 +1015,28 @@ __global__ void apply_partials(const T *__restrict__ part, int S, long stride, i
 // fast.  Measured crossovers: B = 640 (z = 103, fp32), 800 (z = 200, fp32), 580 (z = 176, fp64).
 // CCNN_MBGD_PATH=fused|batched overrides (tests run both on the same inputs).
 constexpr int BATCHED_MIN_B = 768;
+constexpr int TILE_MIN_B = 768;             // from here the sample-tile kernel (tile.hip) takes the per-sample part
 constexpr int BATCHED_MAX_PARTIALS = 256;   // workgroups (= partial gradient rows) of conv_bwd_batch
 constexpr int BATCHED_SPLIT_ROWS = 256;     // rows of the batch one grad_reduce split sums
 constexpr int BATCHED_MAX_SPLITS = 16;
-inline bool use_batched(int B)
+// FUSED: sample_fwd_bwd + grad_reduce.  TILE: tile_fwd_bwd + grad_reduce (+ apply_partials).
+// LAYERS: the five layer kernels + grad_reduce + apply_partials (shapes whose tile does not fit the LDS).
+// CCNN_MBGD_PATH=fused|batched|tile|layers overrides the choice by batch size (tests run every
+// path on the same inputs; "batched" = whatever a large batch would take).
+enum class StepPath { FUSED, TILE, LAYERS };
+template <typename T>
+inline StepPath step_path(int B, const ccnn_dims_t &d, TilePlan *plan)
 {
+    TilePlan tp;
+    const bool fits = tile_plan<T>(B, d, &tp);
+    if (plan && fits) *plan = tp;
     if (const char *e = getenv("CCNN_MBGD_PATH")) {
-        if (!strcmp(e, "batched")) return true;
-        if (!strcmp(e, "fused")) return false;
+        if (!strcmp(e, "fused")) return StepPath::FUSED;
+        if (!strcmp(e, "layers")) return StepPath::LAYERS;
+        if (!strcmp(e, "batched") || !strcmp(e, "tile")) return fits ? StepPath::TILE : StepPath::LAYERS;
     }
-    return B >= BATCHED_MIN_B;
+    if (fits && B >= TILE_MIN_B) return StepPath::TILE;
+    return B >= BATCHED_MIN_B ? StepPath::LAYERS : StepPath::FUSED;
 }
 // Two workgroups per sample in the fused kernel: while both halves of every sample fit the device
 // at once, one workgroup per CU (CCNN_FB_SPLIT=0|1 overrides: diagnostics and tests).
@@ -1068,16 +1080,24 @@ struct MbgdWs {
     T *dp, *parts, *gsum;
     unsigned char *px;
     int *ctr;
+    StepPath path;
+    TilePlan plan;   // path == TILE
+    static int partial_rows(int B, StepPath path, const TilePlan &tp)   // rows of the conv-gradient partials
+    {
+        return path == StepPath::TILE ? tp.tiles : B < BATCHED_MAX_PARTIALS ? B : BATCHED_MAX_PARTIALS;
+    }
     static size_t bytes(int B, const ccnn_dims_t &d)
     {
         size_t b = 0;
         b += align_up((size_t)B * d.pout * sizeof(T));          // pool
         b += 2 * align_up((size_t)B * H * sizeof(T));           // a1, d1
         b += 2 * align_up((size_t)B * d.n_classes * sizeof(T));   // d2, probs
-        if (!use_batched(B)) {
+        TilePlan tp;
+        const StepPath path = step_path<T>(B, d, &tp);
+        if (path == StepPath::FUSED) {
             b += align_up((size_t)B * (F * K + F) * sizeof(T));     // per-sample conv gradient tiles
         } else {
-            const int G = B < BATCHED_MAX_PARTIALS ? B : BATCHED_MAX_PARTIALS;
+            const int G = partial_rows(B, path, tp);
             b += align_up((size_t)G * (F * K + F) * sizeof(T));     // per-workgroup conv gradient partials
             b += align_up((size_t)B * d.pout * sizeof(T));          // dpool
             b += align_up((size_t)B * d.pout);                      // pool winners, one byte each
@@ -1098,10 +1118,11 @@ struct MbgdWs {
         dp = parts = gsum = nullptr;
         px = nullptr;
         ctr = nullptr;
-        if (!use_batched(B)) {
+        path = step_path<T>(B, d, &plan);
+        if (path == StepPath::FUSED) {
             slab = c.take<T>((size_t)B * (F * K + F));
         } else {
-            const int G = B < BATCHED_MAX_PARTIALS ? B : BATCHED_MAX_PARTIALS;
+            const int G = partial_rows(B, path, plan);
             slab = c.take<T>((size_t)G * (F * K + F));
             dp = c.take<T>((size_t)B * d.pout);
             px = c.take<unsigned char>((size_t)B * d.pout);
@@ -1174,6 +1195,12 @@ template <typename T, bool FLIP>
 int mbgd_batched(const T *params, const T *cubes, const int *onehot, long first, int B, int z, const ccnn_dims_t &d,
                  T *grad, UpdateRule<T> upd, double *loss_values, T *probs, MbgdWs<T> &w, hipStream_t st, ccnn_comm *cm)
 {
+    const int G = MbgdWs<T>::partial_rows(B, w.path, w.plan);
+    if (w.path == StepPath::TILE) {
+        if (int e = tile_train<T, FLIP>(params, cubes, onehot, first, B, d, w.plan, w.pool, w.a1, w.d1, w.d2, probs,
+                                        loss_values, w.slab, st))
+            return e;
+    } else {
     if (int e = train_forward<T, FLIP>(params, cubes, onehot, first, B, z, w.pool, w.px, w.a1, w.d1, w.d2, probs,
                                        loss_values, w.ctr, st))
         return e;
@@ -1186,7 +1213,6 @@ int mbgd_batched(const T *params, const T *cubes, const int *onehot, long first,
                (const T *)w.d1, (const T *)w.pool, w.dp, B, d.pout, tpw);
         CCNN_LAUNCH_CHECK();
     }
-    const int G = B < BATCHED_MAX_PARTIALS ? B : BATCHED_MAX_PARTIALS;
     {
         const ConvBwdLds<T> L(d.re, d.mre);
         const bool two = L.bytes(2) <= 150 * 1024;
@@ -1196,6 +1222,7 @@ int mbgd_batched(const T *params, const T *cubes, const int *onehot, long first,
         launch("conv_bwd_batch", kern, dim3(G), dim3(CB_THREADS), smem, st, cubes, first, (const T *)w.dp,
                (const T *)w.pool, (const unsigned char *)w.px, B, d.cube, d.re, d.mre, w.slab);
         CCNN_LAUNCH_CHECK();
+    }
     }
     const int S = batched_splits(B);
     if (S == 1) return launch_grad_reduce<T>(B, d, w, G, 1, grad, 0, upd, cm, st);
@@ -1226,7 +1253,7 @@ int mbgd_impl(const T *params, const T *cubes, const int *onehot, long first, in
     if (!grad && !upd.params) return CCNN_E_INVALID;
     if (ws_bytes < MbgdWs<T>::bytes(B, d)) return CCNN_E_WORKSPACE;
     MbgdWs<T> w(ws, B, d);
-    if (use_batched(B)) return mbgd_batched<T, FLIP>(params, cubes, onehot, first, B, z, d, grad, upd, loss_values, probs, w, st, cm);
+    if (w.path != StepPath::FUSED) return mbgd_batched<T, FLIP>(params, cubes, onehot, first, B, z, d, grad, upd, loss_values, probs, w, st, cm);
     const FusedLayout L = fused_layout<T>(d.re, d.mre);
     // two workgroups per sample while that still fits the chip in one round (one workgroup per CU)
     const bool split = split_samples(B);

@@ -1,0 +1,488 @@
+// The per-sample part of a minibatch step for batches larger than the chip has compute units:
+// ONE launch in which every workgroup takes a tile of up to eight samples through the whole chain
+//
+//   conv + tanh + pool (one wave per sample, MFMA)            convolution, maxpooling
+//   FC1 for the tile as one [ms x Pout] x [Pout x 100] MFMA product, W1 read once per TILE
+//                                                              fully_connect
+//   output layer, softmax, loss, delta2, delta1 (one wave per sample)
+//                                                              output_and_dvalue, loss_function, bp_fully_connect
+//   delta at the pooled features as one [Pout x 100] x [100 x ms] MFMA product, W1 read once per tile
+//                                                              bp_fully_connect (hidden -> pool)
+//   bp_maxpooling scatter + conv gradient (one wave per sample, MFMA), summed over the tile
+//                                                              bp_maxpooling, bp_convolution
+//
+// (gcn_mbgd_fp64.cu:193-496, gcn_mbgd_fp32.cu:207-500).  What reaches memory per sample is what
+// grad_reduce needs for the batch sums (pool, a1, delta1, delta2 rows); the conv gradient leaves as
+// one [F K + F] partial per WORKGROUP.  The per-sample kernel of mbgd.hip walks all of W1 twice
+// per sample, the layer-by-layer kernels hand every intermediate through memory and pay five
+// launches; here the tile's state stays in LDS from the cube to the conv gradient.
+#include <cstdlib>
+
+#include "ccnn_device.h"
+#include "profile.h"
+#include "train_fwd.h"
+
+namespace ccnn {
+
+constexpr int TILE_LDS_LIMIT = 160 * 1024;
+constexpr int TILE_ZN = 128;      // columns of an FC1 partial-sum row (neurons in the permuted order below: 64 T + 4 col + j)
+constexpr int TILE_RED = 1024;    // values per wave in one round of the conv-gradient reduction (2 tap tiles x 2 filter tiles)
+
+// LDS carve (elements of T; every region a multiple of 4 elements so 16-byte accesses stay aligned).
+struct TileLayout {
+    int pld, hld, kc, ldd, cube_pad, b1_len;
+    int pl, a1, d1, w2, b1v, b2v, es, d2, lta, ltb, lab, bs, rb, cube, total;
+    size_t px_off, bytes;
+};
+
+template <typename T>
+__host__ __device__ inline TileLayout tile_layout(int re, int mre, int nwv, int ms, int nch)
+{
+    TileLayout L;
+    const int pout = F * mre, ks = (re + 3) >> 2;
+    L.pld = pout + ((36 - pout % 32) % 32);   // = 4 (mod 32): the 16 sample rows x 4 k of an A fragment spread over all banks
+    L.hld = 108;
+    L.kc = (ks + nch - 1) / nch;              // k-steps (of four positions) per delta-image chunk
+    L.ldd = 4 * L.kc * LDWK;                  // one position-major delta tile [4 kc][16 filters]
+    L.cube_pad = (conv_cube_pad(re) + 3) & ~3;
+    int b1 = WP_LEN;                                              // conv filters (forward)
+    if (b1 < (nwv / 2) * 8 * TILE_ZN) b1 = (nwv / 2) * 8 * TILE_ZN;   // FC1 partial sums [K split][8][128]
+    if (b1 < ms * pout) b1 = ms * pout;                           // delta x tanh' (the conv-bias path)
+    if (b1 < nwv * 2 * L.ldd) b1 = nwv * 2 * L.ldd;               // per-wave delta images
+    if (b1 < nwv * TILE_RED) b1 = nwv * TILE_RED;                 // conv-gradient reduction rounds
+    L.b1_len = (b1 + 3) & ~3;
+    int o = 0;
+    L.pl = o;   o += ms * L.pld;
+    L.a1 = o;   o += ms * L.hld;
+    L.d1 = o;   o += ms * L.hld;
+    L.w2 = o;   o += H * OMAX;
+    L.b1v = o;  o += 104;
+    L.b2v = o;  o += 16;
+    L.es = o;   o += 8 * 16;
+    L.d2 = o;   o += 8 * 16;
+    L.lta = o;  o += 8 * 16;
+    L.ltb = o;  o += 8 * 16;
+    L.lab = o;  o += 8 * 16;    // ints (an int is no larger than T)
+    L.bs = o;   o += 8 * 32;
+    L.rb = o;   o += L.b1_len;
+    L.cube = o; o += nwv * L.cube_pad;
+    L.total = o;
+    L.px_off = (size_t)o * sizeof(T);
+    L.bytes = L.px_off + (size_t)((ms * pout + 15) & ~15);
+    return L;
+}
+
+template <typename T>
+bool tile_plan(int B, const ccnn_dims_t &d, TilePlan *out)
+{
+    // samples per tile: enough to cover the batch with one workgroup per compute unit (256 on the
+    // part this library is built for), at most one per wave
+    int want = (B + 255) / 256;
+    if (want < 1) want = 1;
+    if (want > 8) want = 8;
+    for (int ms = want; ms >= 1; ms--) {
+        for (int nwv = 8; nwv >= 4; nwv >>= 1) {
+            if (ms > nwv) continue;
+            for (int nch = 1; nch <= 8; nch <<= 1) {
+                const TileLayout L = tile_layout<T>(d.re, d.mre, nwv, ms, nch);
+                if (L.bytes <= (size_t)TILE_LDS_LIMIT) {
+                    out->nwv = nwv;
+                    out->ms = ms;
+                    out->nch = nch;
+                    out->smem = L.bytes;
+                    out->tiles = (B + ms - 1) / ms;
+                    return true;
+                }
+            }
+        }
+    }
+    return false;
+}
+template bool tile_plan<float>(int, const ccnn_dims_t &, TilePlan *);
+template bool tile_plan<double>(int, const ccnn_dims_t &, TilePlan *);
+
+// Four consecutive values of T from a 16-byte aligned address.
+template <typename T>
+struct Quad;
+template <>
+struct Quad<float> {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    v4 v;
+    __device__ __forceinline__ void load(const float *p) { v = *reinterpret_cast<const v4 *>(p); }
+    __device__ __forceinline__ float operator[](int j) const { return v[j]; }
+};
+template <>
+struct Quad<double> {
+    typedef double v2 __attribute__((ext_vector_type(2)));
+    v2 lo, hi;
+    __device__ __forceinline__ void load(const double *p)
+    {
+        lo = *reinterpret_cast<const v2 *>(p);
+        hi = *reinterpret_cast<const v2 *>(p + 2);
+    }
+    __device__ __forceinline__ double operator[](int j) const { return j < 2 ? lo[j] : hi[j - 2]; }
+};
+
+// NO: the class count when it is the reference's 13 (compile-time then), 0 for any other (d.n_classes).
+template <typename T, bool FLIP, int NO>
+__global__ __launch_bounds__(512) void tile_fwd_bwd(const T *__restrict__ params, const T *__restrict__ cubes,
+                                                    const int *__restrict__ onehot, long first, int B, int ms, int nch,
+                                                    ccnn_dims_t d, T *__restrict__ pool_g, T *__restrict__ a1_g,
+                                                    T *__restrict__ d1_g, T *__restrict__ d2_g, T *__restrict__ probs_g,
+                                                    double *__restrict__ loss_values, T *__restrict__ part)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename Vec16<T>::type V;
+    constexpr int VW = Vec16<T>::W;
+    const int nt = blockDim.x, nwv = nt >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const int re = d.re, mre = d.mre, pout = d.pout, no = NO ? NO : d.n_classes;
+    const TileLayout L = tile_layout<T>(re, mre, nwv, ms, nch);
+    T *base = reinterpret_cast<T *>(smem);
+    T *pl = base + L.pl, *a1s = base + L.a1, *d1s = base + L.d1, *w2s = base + L.w2, *b1s = base + L.b1v;
+    T *b2s = base + L.b2v, *es = base + L.es, *d2s = base + L.d2, *lta = base + L.lta, *ltb = base + L.ltb;
+    int *labs = reinterpret_cast<int *>(base + L.lab);
+    T *bs = base + L.bs, *rb = base + L.rb;
+    T *cube = base + L.cube + wave * L.cube_pad;
+    unsigned char *px = reinterpret_cast<unsigned char *>(smem + L.px_off);
+
+    const int r0 = blockIdx.x * ms;
+    const int nb = min(ms, B - r0);
+    const bool mine = wave < nb;                 // this wave owns sample r0 + wave
+    const long row = r0 + (mine ? wave : 0);     // (a valid row for the loads of a wave that owns none)
+    T *plr = pl + (mine ? wave : 0) * L.pld;
+    unsigned char *pxr = px + (mine ? wave : 0) * pout;
+    const T *W1 = params + d.off_w1;
+
+    // ---- stage: this wave's cube, the conv filters, the output layer ------------------------
+    {
+        const T *src = cubes + (first + row) * (long)d.cube;
+        T t0[16];   // the first 1024 cube elements fly while the filters are staged
+#pragma unroll
+        for (int u = 0; u < 16; u++) t0[u] = src[min(u * 64 + lane, d.cube - 1)];
+        stage_filters_packed<T, FLIP>(params + d.off_w0, rb, tid, nt);
+        for (int e = d.cube + lane; e < L.cube_pad; e += 64) cube[e] = 0;
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int e = u * 64 + lane;
+            if (e < d.cube) cube[e] = t0[u];
+        }
+        for (int e0 = 1024; e0 < d.cube; e0 += 1024) {
+            T t[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) t[u] = src[min(e0 + u * 64 + lane, d.cube - 1)];
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const int e = e0 + u * 64 + lane;
+                if (e < d.cube) cube[e] = t[u];
+            }
+        }
+        for (int e = tid; e < H * no; e += nt) w2s[e] = params[d.off_w2 + e];
+        if (tid < H) b1s[tid] = params[d.off_b1 + tid];
+        if (tid < no) b2s[tid] = params[d.off_b2 + tid];
+    }
+    const T bias0 = params[d.off_b0 + col];
+    const T biasx = params[d.off_b0 + 16 + (col & 3)];
+    const int lab_g = onehot[(first + row) * no + min(lane, no - 1)];   // needed deep in the chain: fetched now
+    __syncthreads();
+
+    // ---- conv + tanh + pool: one wave per sample ----------------------------------------------
+    if (mine) {
+        conv_pool_wave<T>(cube, rb, re, bias0, biasx, lane, [&](int f, int m, T v, int bt) {
+            plr[f * mre + m] = v;
+            pxr[f * mre + m] = (unsigned char)(bt - 2 * m);   // which member of the pair won
+        });
+        wave_sync();
+        const V *sv = reinterpret_cast<const V *>(plr);
+        V *dv = reinterpret_cast<V *>(pool_g + row * pout);
+        for (int o = lane; o < pout / VW; o += 64) dv[o] = sv[o];   // pout = 20 mre: whole 16-byte vectors
+    }
+    __syncthreads();
+
+    // ---- FC1: z1[s][n] = sum_p pool[s][p] W1[n + 100 p] ----------------------------------------
+    // Rows of the MFMA tile = samples, K = pooled features, split over the waves' K ranges; the
+    // columns are neurons in a permuted order so that every lane fetches W1 in 16-byte pieces: wave
+    // half T covers neurons 64 T .. 64 T + 63, column c of its j-th tile is neuron 64 T + 4 c + j,
+    // i.e. one vector load feeds four tiles.  A row of W1 (400 bytes) is fetched exactly once per
+    // workgroup: 256 bytes by a T = 0 wave, 144 by its T = 1 partner.
+    {
+        const int T2 = wave & 1, q = wave >> 1, KQ = nwv >> 1;
+        const int ks1 = pout >> 2, kper = (ks1 + KQ - 1) / KQ;
+        const int s_lo = q * kper, s_hi = min(s_lo + kper, ks1);
+        const int ncol = 64 * T2 + 4 * col;
+        const bool nvalid = ncol + 3 < H;
+        const T *wp = W1 + (nvalid ? ncol : 0) + kq * H;
+        const T *ap = pl + min(col, ms - 1) * L.pld + kq;
+        typename Mma<T>::acc_t acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[j] = typename Mma<T>::acc_t{0, 0, 0, 0};
+        constexpr int U = sizeof(T) == 4 ? 16 : 8;   // k-steps of W1 in flight
+        for (int s = s_lo; s < s_hi; s += U) {
+            Quad<T> w[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) w[u].load(wp + 4L * min(s + u, s_hi - 1) * H);   // clamped, unconditional
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (s + u < s_hi) {
+                    const T a = ap[4 * (s + u)];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) acc[j] = Mma<T>::mma(a, w[u][j], acc[j]);
+                }
+            }
+        }
+        T *zp = rb;   // [KQ][8][TILE_ZN] (the filters are dead)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int sr = Mma<T>::row(lane, r);
+                if (sr < ms && nvalid) zp[(q * 8 + sr) * TILE_ZN + ncol + j] = acc[j][r];
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < nb * H; e += nt) {
+            const int s = e / H, n = e - s * H;
+            T z = 0;
+            for (int qq = 0; qq < KQ; qq++) z = z + zp[(qq * 8 + s) * TILE_ZN + n];
+            const T a = act(z + b1s[n]);   // gcn_mbgd_fp64.cu:302
+            a1s[s * L.hld + n] = a;
+            a1_g[(long)(r0 + s) * H + n] = a;
+        }
+        __syncthreads();
+    }
+
+    // The first W1 rows of the delta-pool product fly during the head (which needs no memory).
+    constexpr int NG = (H + 4 * VW - 1) / (4 * VW);   // vectors per lane along n
+    const int ntp = (pout + 15) >> 4;                 // 16-feature tiles of the product
+    auto w1_tile = [&](int pt, V(&a)[NG]) {           // rows pt*16 + col of W1 (clamped, unconditional), k order permuted as below
+        const int prow = min(pt * 16 + col, pout - 1);
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            const int n = VW * kq + 4 * VW * g;
+            a[g] = reinterpret_cast<const V *>(W1 + (long)prow * H)[min(n, H - VW) / VW];
+            if (n >= H) a[g] = V{};
+        }
+    };
+    V wa[NG], wb[NG];
+    w1_tile(min(wave, ntp - 1), wa);
+    w1_tile(min(wave + nwv, ntp - 1), wb);
+
+    // ---- output layer, softmax, loss, delta2, delta1: one wave per sample -----------------------
+    if (mine) {
+        const T *ar = a1s + wave * L.hld;
+        const int o = lane & 15, pt4 = lane >> 4;   // output o, a quarter of the hidden units each
+        const int oc = min(o, no - 1);
+        T mid = 0;
+        for (int i = pt4 * 25; i < pt4 * 25 + 25; i++) mid = mid + w2s[oc + i * no] * ar[i];
+        mid += __shfl_xor(mid, 16);
+        mid += __shfl_xor(mid, 32);
+        const T e = rexp(mid + b2s[oc]);
+        if (lane < no) es[wave * 16 + lane] = e;
+        wave_sync();
+        const T p = e / tree_n(es + wave * 16, no);
+        if (lane < no) {
+            if (probs_g) probs_g[row * no + lane] = p;
+            const T dv = (p - lab_g) / no;   // gcn_mbgd_fp64.cu:352
+            d2s[wave * 16 + lane] = dv;
+            d2_g[row * no + lane] = dv;
+            loss_terms(p, lab_g, &lta[wave * 16 + lane], &ltb[wave * 16 + lane]);
+            labs[wave * 16 + lane] = lab_g;
+        }
+        wave_sync();
+        if (lane == 63) loss_values[row] = loss_sum(lta + wave * 16, ltb + wave * 16, labs + wave * 16, no);
+        T dd[OMAX];   // entries past the class count are never read by the tree
+#pragma unroll
+        for (int oo = 0; oo < OMAX; oo++) dd[oo] = d2s[wave * 16 + oo];
+        for (int n = lane; n < H; n += 64) {
+            // bp_fully_connect(out -> hidden), gcn_mbgd_fp64.cu:416-434: class-wide tree
+            T prod[OMAX];
+#pragma unroll
+            for (int oo = 0; oo < OMAX; oo++) prod[oo] = w2s[min(oo, no - 1) + n * no] * dd[oo];
+            const T a = ar[n];
+            const T dv = tree_n(prod, no) * (1 + a) * (1 - a);
+            d1s[wave * L.hld + n] = dv;
+            d1_g[row * H + n] = dv;
+        }
+    }
+    __syncthreads();
+
+    // ---- delta at the pooled features: dp[s][p] = (sum_n W1[n + 100 p] d1[s][n]) (1 + pool)(1 - pool) ----
+    // Rows of the MFMA tile = 16 pooled features (A = 16 rows of W1), columns = samples (B = rows of
+    // d1).  Both operands are contiguous along n, so each lane fetches 16-byte vectors and the
+    // product's k order is permuted to match: k-step s of lane group kq takes
+    // n = VW kq + (s mod VW) + 4 VW (s / VW) - the same permutation on both sides.
+    // dp replaces pool in LDS; dp x tanh' (the reference's second tanh' of the conv-bias path,
+    // gcn_mbgd_fp64.cu:487-488; at a winner the conv output is the pooled value) goes to dsm.
+    T *dsm = rb;   // [ms][pout] (the FC1 partial sums are dead)
+    {
+        V w[NG];
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            const int n = VW * kq + 4 * VW * g;
+            w[g] = *reinterpret_cast<const V *>(d1s + min(col, ms - 1) * L.hld + min(n, H - VW));   // lanes past n = 100 meet a zero in a[]
+        }
+        auto product = [&](int pt, const V(&a)[NG]) {
+            typename Mma<T>::acc_t acc = {0, 0, 0, 0};
+#pragma unroll
+            for (int g = 0; g < NG; g++)
+#pragma unroll
+                for (int j = 0; j < VW; j++) acc = Mma<T>::mma(a[g][j], w[g][j], acc);
+            // lane holds sample col, features pt*16 + Mma::row(lane, 0..3)
+            if (col < nb) {
+                if (sizeof(T) == 4) {
+                    // f32 result map: rows 4 kq .. 4 kq + 3 are consecutive features: one 16-byte access each way
+                    const int p = pt * 16 + 4 * kq;
+                    if (p < pout) {
+                        V *pp = reinterpret_cast<V *>(pl + col * L.pld + p);
+                        const V pv = *pp;
+                        V o, o2;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const T t1 = (1 + pv[r % VW]) * (1 - pv[r % VW]);
+                            o[r % VW] = acc[r] * t1;
+                            o2[r % VW] = o[r % VW] * t1;
+                        }
+                        *pp = o;
+                        *reinterpret_cast<V *>(dsm + col * pout + p) = o2;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int p = pt * 16 + Mma<T>::row(lane, r);
+                        if (p < pout) {
+                            const T pv = pl[col * L.pld + p];
+                            const T t1 = (1 + pv) * (1 - pv);
+                            const T o = acc[r] * t1;
+                            pl[col * L.pld + p] = o;
+                            dsm[col * pout + p] = o * t1;
+                        }
+                    }
+                }
+            }
+        };
+        // two tiles ahead: the loads of tile pt + 2 nwv are issued before tile pt is multiplied
+        for (int pt = wave; pt < ntp; pt += 2 * nwv) {
+            V wc[NG];
+#pragma unroll
+            for (int g = 0; g < NG; g++) wc[g] = wa[g];
+            w1_tile(min(pt + 2 * nwv, ntp - 1), wa);
+            product(pt, wc);
+            if (pt + nwv < ntp) {
+#pragma unroll
+                for (int g = 0; g < NG; g++) wc[g] = wb[g];
+                w1_tile(min(pt + 3 * nwv, ntp - 1), wb);
+                product(pt + nwv, wc);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- conv-bias path: per sample and filter, the sum of dp x tanh' over the pooled positions ----
+    if (mine) {
+        const int f = lane / 3, third = lane - 3 * f;
+        T s = 0;
+        if (f < F)
+            for (int m = third; m < mre; m += 3) s = s + dsm[wave * pout + f * mre + m];
+        const T s1 = __shfl_down(s, 1), s2 = __shfl_down(s, 2);
+        if (third == 0 && f < F) bs[wave * 32 + f] = s + s1 + s2;
+    }
+    __syncthreads();   // dsm is dead: its region becomes the delta images
+
+    // ---- bp_maxpooling scatter + conv gradient of this wave's sample ----------------------------
+    // dW0[f][tap] = sum_t delta[f][t] cube[18 t + tap]: A = position-major delta tiles [4 kc][16] (two:
+    // filters 0..15 and 16..31), B = the cube, 11 tap tiles; the delta image covers kc k-steps of
+    // positions at a time (nch chunks) where a whole one would not fit.
+    typename Mma<T>::acc_t c0[11], c1[11];
+#pragma unroll
+    for (int j = 0; j < 11; j++) c0[j] = c1[j] = typename Mma<T>::acc_t{0, 0, 0, 0};
+    if (mine) {
+        const int ks = (re + 3) >> 2;
+        T *dl = rb + wave * 2 * L.ldd;
+        for (int c = 0; c < nch; c++) {
+            const int t_lo = 4 * L.kc * c;
+            const int nks = min(L.kc, ks - L.kc * c);
+            if (nks <= 0) break;
+            for (int e = lane; e < 2 * L.ldd; e += 64) dl[e] = 0;
+            wave_sync();
+            for (int p = lane; p < pout; p += 64) {
+                const int f = p / mre, m = p - f * mre;
+                const int tt = 2 * m + (int)pxr[p] - t_lo;
+                if (tt >= 0 && tt < 4 * L.kc) dl[(f >> 4) * L.ldd + tt * LDWK + (f & 15)] = plr[p];
+            }
+            wave_sync();
+            const T *ap0 = dl + kq * LDWK + col, *ap1 = ap0 + L.ldd;
+            const T *bp = cube + WSTEP * (t_lo + kq) + col;
+#pragma unroll 2
+            for (int s = 0; s < nks; s++) {
+                const T a0 = ap0[4 * s * LDWK], a1 = ap1[4 * s * LDWK];
+                T b[11];
+#pragma unroll
+                for (int j = 0; j < 11; j++) b[j] = bp[4 * s * WSTEP + 16 * j];
+#pragma unroll
+                for (int j = 0; j < 11; j++) {
+                    c0[j] = Mma<T>::mma(a0, b[j], c0[j]);
+                    c1[j] = Mma<T>::mma(a1, b[j], c1[j]);
+                }
+            }
+            wave_sync();   // the image is zeroed again next round
+        }
+    }
+    __syncthreads();
+
+    // ---- the tile's conv gradient: the waves' accumulators added in sample order, two tap tiles a round ----
+    T *out = part + (long)blockIdx.x * (F * K + F);
+#pragma unroll
+    for (int g = 0; g < 6; g++) {
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+            const int j = 2 * g + jj;
+            if (j < 11) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    rb[wave * TILE_RED + (jj * 2 + 0) * 256 + r * 64 + lane] = c0[j][r];
+                    rb[wave * TILE_RED + (jj * 2 + 1) * 256 + r * 64 + lane] = c1[j][r];
+                }
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < TILE_RED; e += nt) {
+            const int jj = e >> 9, ft = (e >> 8) & 1, r = (e >> 6) & 3, ln = e & 63;
+            const int j = 2 * g + jj;
+            const int tap = 16 * j + (ln & 15), f = 16 * ft + Mma<T>::row(ln, r);
+            if (j < 11 && tap < K && f < F) {
+                T s = 0;
+                for (int w = 0; w < nwv; w++) s = s + rb[w * TILE_RED + e];
+                out[f * K + tap] = s / re;   // gcn_mbgd_fp64.cu:491
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < F) {
+        T s = 0;
+        for (int w = 0; w < nb; w++) s = s + bs[w * 32 + tid];
+        out[F * K + tid] = s / re;
+    }
+}
+
+template <typename T, bool FLIP>
+int tile_train(const T *params, const T *cubes, const int *onehot, long first, int B, const ccnn_dims_t &d,
+               const TilePlan &plan, T *pool, T *a1, T *d1, T *d2, T *probs, double *loss_values, T *part,
+               hipStream_t st)
+{
+    const bool c13 = d.n_classes == CCNN_CLASSES;
+    auto kern = c13 ? tile_fwd_bwd<T, FLIP, CCNN_CLASSES> : tile_fwd_bwd<T, FLIP, 0>;
+    if (int e = allow_smem(kern, plan.smem)) return e;
+    launch("tile_fwd_bwd", kern, dim3(plan.tiles), dim3(64 * plan.nwv), plan.smem, st, params, cubes, onehot, first, B,
+           plan.ms, plan.nch, d, pool, a1, d1, d2, probs, loss_values, part);
+    CCNN_LAUNCH_CHECK();
+    return 0;
+}
+template int tile_train<float, true>(const float *, const float *, const int *, long, int, const ccnn_dims_t &,
+                                     const TilePlan &, float *, float *, float *, float *, float *, double *, float *,
+                                     hipStream_t);
+template int tile_train<double, false>(const double *, const double *, const int *, long, int, const ccnn_dims_t &,
+                                       const TilePlan &, double *, double *, double *, double *, double *, double *,
+                                       double *, hipStream_t);
+
+}  // namespace ccnn

@@ -14,4 +14,21 @@ template <typename T, bool FLIP>
 int train_forward(const T *params, const T *cubes, const int *onehot, long first, int B, int z, T *pool,
                   unsigned char *px, T *a1, T *d1, T *d2, T *probs, double *loss_values, int *ctr, hipStream_t st);
 
+// The whole per-sample part of a step in one launch, a tile of up to eight samples per workgroup
+// (tile.hip): pool, a1, d1, d2 rows (+ probs, loss_values) as train_forward leaves them, and one
+// conv-gradient partial [F K + F] per workgroup in part[plan.tiles][F K + F].
+struct TilePlan {
+    int nwv, ms, nch;   // waves per workgroup, samples per tile, position chunks of the delta image
+    size_t smem;        // dynamic LDS bytes
+    int tiles;          // workgroups = rows of `part`
+};
+// false: the shape does not fit the LDS in any configuration (the caller uses the layer kernels).
+// Depends on B, the geometry and T only, never on the device, so workspace sizes can be computed anywhere.
+template <typename T>
+bool tile_plan(int B, const ccnn_dims_t &d, TilePlan *out);
+template <typename T, bool FLIP>
+int tile_train(const T *params, const T *cubes, const int *onehot, long first, int B, const ccnn_dims_t &d,
+               const TilePlan &plan, T *pool, T *a1, T *d1, T *d2, T *probs, double *loss_values, T *part,
+               hipStream_t st);
+
 }  // namespace ccnn

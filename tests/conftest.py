@@ -25,9 +25,11 @@ def golden():
     return load
 
 
-@pytest.fixture(params=["fused", "batched"])
+@pytest.fixture(params=["fused", "tile", "layers"])
 def mbgd_path(request, monkeypatch):
-    """Runs a test once per implementation of the minibatch step: the fused per-sample kernel and
-    the batched layer kernels (the library picks by batch size unless CCNN_MBGD_PATH says otherwise)."""
+    """Runs a test once per implementation of the minibatch step: the fused per-sample kernel, the
+    sample-tile kernel and the layer kernels (the library picks by batch size and shape unless
+    CCNN_MBGD_PATH says otherwise; "tile" falls back to the layer kernels for shapes whose tile
+    does not fit the LDS)."""
     monkeypatch.setenv("CCNN_MBGD_PATH", request.param)
     return request.param

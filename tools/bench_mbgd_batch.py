@@ -1,5 +1,5 @@
 """Step time of ccnn_mbgd_step_f32 against the batch size, for both implementations of the
-step (CCNN_MBGD_PATH=fused|batched), with the per-kernel times from the library's hooks.
+step (CCNN_MBGD_PATH=fused|tile|layers), with the per-kernel times from the library's hooks.
     python tools/bench_mbgd_batch.py [workload] [dtype]"""
 import os
 import sys
@@ -25,7 +25,7 @@ oh = np.zeros((n, 13), dtype=np.int32)
 oh[np.arange(n), rng.integers(0, 13, n)] = 1
 oh = torch.from_numpy(oh).cuda()
 p0 = torch.from_numpy(prep.init_params(z, dtype, d.pout)).cuda()
-for path in ("fused", "batched"):
+for path in (os.environ.get("BENCH_PATHS", "fused,tile,layers").split(",")):
     os.environ["CCNN_MBGD_PATH"] = path
     for B in (64, 128, 256, 512, 1024, 2048, 4096):
         if path == "fused" and B > 1024:
