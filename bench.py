@@ -40,6 +40,8 @@ def kernel_work(d, z):
     return {
         # conv fwd + conv bwd, FC1 fwd + delta, FC2 fwd + delta
         "sample_fwd_bwd": ("mfma", 2 * conv + 2 * fc1 + 4.0 * 1300),
+        # the same chain for a tile of samples per workgroup (large batches)
+        "tile_fwd_bwd": ("mfma", 2 * conv + 2 * fc1 + 4.0 * 1300),
         # dW1 = pool^T d1, dW2 = a1^T d2
         "grad_reduce": ("mfma", fc1 + 2.0 * 1300),
         "conv_pool_fwd": ("mfma", conv),
@@ -98,9 +100,9 @@ def kernel_rows(rep, d, z, pixels, passes=None, world=1, splits=1):
     return rows
 
 
-TRAIN_KERNELS = ("sample_fwd_bwd", "grad_reduce", "update_f32_kernel", "allreduce_apply", "conv_pool_fwd_train",
+TRAIN_KERNELS = ("sample_fwd_bwd", "tile_fwd_bwd", "grad_reduce", "update_f32_kernel", "allreduce_apply", "conv_pool_fwd_train",
                  "fc_head_fwd_train", "dpool_bwd", "conv_bwd_batch", "apply_partials")
-BATCHED_MIN_B = 768      # the library's choice between its two implementations of the step (mbgd.hip)
+STEP_PATHS = {0: "fused per-sample kernel", 1: "sample-tile kernel", 2: "batched layer kernels"}   # ccnn_mbgd_path
 
 
 def dominant(rows, workload, B):
@@ -143,7 +145,7 @@ def train_rate(params_h, cubes, onehot_d, z, B, steps, workload, profile=True):
     dt = timed_steps(step, steps)
     assert torch.isfinite(p).all(), "training diverged"
     out = {"batch": B, "train_pixels_per_s": round(B / dt, 1), "us_per_step": round(dt * 1e6, 2),
-           "path": "batched layer kernels" if B >= BATCHED_MIN_B else "fused per-sample kernel"}
+           "path": STEP_PATHS.get(L.load().ccnn_mbgd_path(B, z, 4), "?")}
     if profile:
         L.profile_enable(True)
         psteps = min(steps, 100)

@@ -402,46 +402,67 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// Workgroup barrier that orders LDS traffic only: global stores still in flight (results nobody in
+// the workgroup reads back) are not waited for, where __syncthreads() stalls every wave until the
+// last store has been acknowledged by memory.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // Conv forward + tanh + pool of ONE LDS-resident sample by ONE wave: ceil(re/16) chains of 43
 // k-steps for filters 0..15 (rows = 16 positions) and ceil(ceil(re/4)/16) chains of 57 k-steps
 // for filters 16..19 on the packed tile (rows = 16 consecutive j; columns = 4 shifts x 4
 // filters, so both members of a pool pair sit in one row, 4 columns apart).
 // wl = [172][LDWK] filters 0..15 | [228][LDWK] packed tile; cube zero-padded to
 // conv_cube_pad(re).  put(f, m, value, winning position).
+// Chains per sample: ceil(re/16) over filters 0..15, then the packed-tile chains.
+__host__ __device__ inline int conv_chains(int re) { return conv_mtiles(re) + (((re - 1) >> 2) >> 4) + 1; }
+
+// Chain c of a sample (c < conv_chains(re)) by one wave.
+template <typename T, typename Put>
+__device__ __forceinline__ void conv_pool_chain(const T *cube, const T *wl, int re, int c, T bias0, T biasx, int lane,
+                                                Put put)
+{
+    const int col = lane & 15, kq = lane >> 4;
+    const int mt = conv_mtiles(re);
+    const T *bp0 = wl + kq * LDWK + col;
+    if (c < mt) {
+        const T *ap = cube + WSTEP * (c * 16 + col) + kq;
+        const typename Mma<T>::acc_t acc = mma_chain<T, KSTEPS0>(ap, bp0);
+        pool_tile(acc, bias0, col, true, c * 16, re, lane, put);
+        return;
+    }
+    const int tau = c - mt, jmax = (re - 1) >> 2;
+    const int g = col >> 2, fl = col & 3;
+    const int j = min(tau * 16 + col, jmax);   // clamped: rows past the end are discarded below
+    const T *ap = cube + 4 * WSTEP * j + kq;
+    const typename Mma<T>::acc_t acc = mma_chain<T, KSTEPSX>(ap, bp0 + WL_TILE);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int t = 4 * (tau * 16 + Mma<T>::row(lane, r)) + g;
+        const T v = act(acc[r] + biasx);
+        const T vn = __shfl_xor(v, 4);           // same row, shift g ^ 1: the pool partner
+        if (!(g & 1) && t < re) {
+            T best = v;
+            int bt = t;
+            if (t + 1 < re && best < vn) {       // strict '<': the first maximum wins
+                best = vn;
+                bt = t + 1;
+            }
+            put(16 + fl, t >> 1, best, bt);
+        }
+    }
+}
+
 template <typename T, typename Put>
 __device__ __forceinline__ void conv_pool_wave(const T *cube, const T *wl, int re, T bias0, T biasx, int lane,
                                                Put put)
 {
-    const int col = lane & 15, kq = lane >> 4;
-    const int mt = conv_mtiles(re);
-    const int jmax = (re - 1) >> 2;
-    const T *bp0 = wl + kq * LDWK + col;
-    for (int tile = 0; tile < mt; tile++) {
-        const T *ap = cube + WSTEP * (tile * 16 + col) + kq;
-        const typename Mma<T>::acc_t acc = mma_chain<T, KSTEPS0>(ap, bp0);
-        pool_tile(acc, bias0, col, true, tile * 16, re, lane, put);
-    }
-    const int g = col >> 2, fl = col & 3;
-    for (int tau = 0; 16 * tau <= jmax; tau++) {
-        const int j = min(tau * 16 + col, jmax);   // clamped: rows past the end are discarded below
-        const T *ap = cube + 4 * WSTEP * j + kq;
-        const typename Mma<T>::acc_t acc = mma_chain<T, KSTEPSX>(ap, bp0 + WL_TILE);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int t = 4 * (tau * 16 + Mma<T>::row(lane, r)) + g;
-            const T v = act(acc[r] + biasx);
-            const T vn = __shfl_xor(v, 4);           // same row, shift g ^ 1: the pool partner
-            if (!(g & 1) && t < re) {
-                T best = v;
-                int bt = t;
-                if (t + 1 < re && best < vn) {       // strict '<': the first maximum wins
-                    best = vn;
-                    bt = t + 1;
-                }
-                put(16 + fl, t >> 1, best, bt);
-            }
-        }
-    }
+    const int nc = conv_chains(re);
+    for (int c = 0; c < nc; c++) conv_pool_chain<T>(cube, wl, re, c, bias0, biasx, lane, put);
 }
 
 // Stages the 20 x 171 filters as conv_pool_wave wants them (zero taps and columns included), by a

@@ -1015,7 +1015,7 @@ __global__ void apply_partials(const T *__restrict__ part, int S, long stride, i
 // fast.  Measured crossovers: B = 640 (z = 103, fp32), 800 (z = 200, fp32), 580 (z = 176, fp64).
 // CCNN_MBGD_PATH=fused|batched overrides (tests run both on the same inputs).
 constexpr int BATCHED_MIN_B = 768;
-constexpr int TILE_MIN_B = 768;             // from here the sample-tile kernel (tile.hip) takes the per-sample part
+constexpr int TILE_MIN_B = 576;             // from here the sample-tile kernel (tile.hip) takes the per-sample part
 constexpr int BATCHED_MAX_PARTIALS = 256;   // workgroups (= partial gradient rows) of conv_bwd_batch
 constexpr int BATCHED_SPLIT_ROWS = 256;     // rows of the batch one grad_reduce split sums
 constexpr int BATCHED_MAX_SPLITS = 16;
@@ -1099,8 +1099,10 @@ struct MbgdWs {
         } else {
             const int G = partial_rows(B, path, tp);
             b += align_up((size_t)G * (F * K + F) * sizeof(T));     // per-workgroup conv gradient partials
-            b += align_up((size_t)B * d.pout * sizeof(T));          // dpool
-            b += align_up((size_t)B * d.pout);                      // pool winners, one byte each
+            if (path == StepPath::LAYERS) {
+                b += align_up((size_t)B * d.pout * sizeof(T));      // dpool
+                b += align_up((size_t)B * d.pout);                  // pool winners, one byte each
+            }
             b += align_up((size_t)batched_splits(B) * d.nparams * sizeof(T));   // grad_reduce's batch splits
             b += align_up((size_t)d.nparams * sizeof(T));           // summed gradient (multi-GPU exchange)
             b += align_up(TRAIN_CTR_INTS * sizeof(int));
@@ -1124,8 +1126,10 @@ struct MbgdWs {
         } else {
             const int G = partial_rows(B, path, plan);
             slab = c.take<T>((size_t)G * (F * K + F));
-            dp = c.take<T>((size_t)B * d.pout);
-            px = c.take<unsigned char>((size_t)B * d.pout);
+            if (path == StepPath::LAYERS) {
+                dp = c.take<T>((size_t)B * d.pout);
+                px = c.take<unsigned char>((size_t)B * d.pout);
+            }
             parts = c.take<T>((size_t)batched_splits(B) * d.nparams);
             gsum = c.take<T>((size_t)d.nparams);
             ctr = c.take<int>(TRAIN_CTR_INTS);
@@ -1324,6 +1328,13 @@ size_t ccnn_mbgd_workspace_bytes(int B, int z, int elem_size)
     ccnn_dims_t d;
     if (make_dims(z, &d) || B <= 0) return 0;
     return elem_size == 8 ? MbgdWs<double>::bytes(B, d) : MbgdWs<float>::bytes(B, d);
+}
+
+int ccnn_mbgd_path(int B, int z, int elem_size)
+{
+    ccnn_dims_t d;
+    if (make_dims(z, &d) || B <= 0 || (elem_size != 4 && elem_size != 8)) return CCNN_E_INVALID;
+    return (int)(elem_size == 8 ? step_path<double>(B, d, nullptr) : step_path<float>(B, d, nullptr));
 }
 
 int ccnn_mbgd_grad_f32(const float *params, const float *cubes, const int *onehot, long first, int B,

@@ -8,7 +8,7 @@
 //                                                              output_and_dvalue, loss_function, bp_fully_connect
 //   delta at the pooled features as one [Pout x 100] x [100 x ms] MFMA product, W1 read once per tile
 //                                                              bp_fully_connect (hidden -> pool)
-//   bp_maxpooling scatter + conv gradient (one wave per sample, MFMA), summed over the tile
+//   bp_maxpooling scatter + conv gradient (MFMA), summed over the tile in the accumulators
 //                                                              bp_maxpooling, bp_convolution
 //
 // (gcn_mbgd_fp64.cu:193-496, gcn_mbgd_fp32.cu:207-500).  What reaches memory per sample is what
@@ -22,11 +22,28 @@
 #include "profile.h"
 #include "train_fwd.h"
 
+// Diagnostic builds only (-DCCNN_TILE_TIMING): thread 0 of workgroup 5 stamps the 100 MHz wall clock
+// at TT(k); ccnn_debug_tile_ticks() returns the stamps of the last launch.
+#ifdef CCNN_TILE_TIMING
+__device__ unsigned long long g_tile_ticks[32];
+#define TT(k)                                                                        \
+    do {                                                                             \
+        if (blockIdx.x == 5 && threadIdx.x == 0) g_tile_ticks[k] = wall_clock64();   \
+    } while (0)
+extern "C" int ccnn_debug_tile_ticks(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_ticks), sizeof(unsigned long long) * 32);
+}
+#else
+#define TT(k) do { } while (0)
+#endif
+
 namespace ccnn {
 
 constexpr int TILE_LDS_LIMIT = 160 * 1024;
+constexpr int TILE_RED = 2048;    // values per wave in one round of the conv-gradient reduction (4 tap tiles x 2 filter tiles)
+constexpr int TILE_ACC_MS = 4;    // up to this many samples per tile the conv gradient is summed in the accumulators
 constexpr int TILE_ZN = 128;      // columns of an FC1 partial-sum row (neurons in the permuted order below: 64 T + 4 col + j)
-constexpr int TILE_RED = 1024;    // values per wave in one round of the conv-gradient reduction (2 tap tiles x 2 filter tiles)
 
 // LDS carve (elements of T; every region a multiple of 4 elements so 16-byte accesses stay aligned).
 struct TileLayout {
@@ -49,7 +66,8 @@ __host__ __device__ inline TileLayout tile_layout(int re, int mre, int nwv, int 
     if (b1 < (nwv / 2) * 8 * TILE_ZN) b1 = (nwv / 2) * 8 * TILE_ZN;   // FC1 partial sums [K split][8][128]
     if (b1 < ms * pout) b1 = ms * pout;                           // delta x tanh' (the conv-bias path)
     if (b1 < nwv * 2 * L.ldd) b1 = nwv * 2 * L.ldd;               // per-wave delta images
-    if (b1 < nwv * TILE_RED) b1 = nwv * TILE_RED;                 // conv-gradient reduction rounds
+    if (ms > TILE_ACC_MS && b1 + nwv * L.cube_pad < nwv * TILE_RED)
+        b1 = nwv * (TILE_RED - L.cube_pad);                       // conv-gradient reduction rounds (they run over into the cubes)
     L.b1_len = (b1 + 3) & ~3;
     int o = 0;
     L.pl = o;   o += ms * L.pld;
@@ -124,8 +142,8 @@ struct Quad<double> {
 };
 
 // NO: the class count when it is the reference's 13 (compile-time then), 0 for any other (d.n_classes).
-template <typename T, bool FLIP, int NO>
-__global__ __launch_bounds__(512) void tile_fwd_bwd(const T *__restrict__ params, const T *__restrict__ cubes,
+template <typename T, bool FLIP, int NO, int NWV>
+__global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ params, const T *__restrict__ cubes,
                                                     const int *__restrict__ onehot, long first, int B, int ms, int nch,
                                                     ccnn_dims_t d, T *__restrict__ pool_g, T *__restrict__ a1_g,
                                                     T *__restrict__ d1_g, T *__restrict__ d2_g, T *__restrict__ probs_g,
@@ -134,7 +152,7 @@ __global__ __launch_bounds__(512) void tile_fwd_bwd(const T *__restrict__ params
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Vec16<T>::type V;
     constexpr int VW = Vec16<T>::W;
-    const int nt = blockDim.x, nwv = nt >> 6;
+    constexpr int nt = 64 * NWV, nwv = NWV;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15, kq = lane >> 4;
     const int re = d.re, mre = d.mre, pout = d.pout, no = NO ? NO : d.n_classes;
@@ -155,13 +173,52 @@ __global__ __launch_bounds__(512) void tile_fwd_bwd(const T *__restrict__ params
     unsigned char *pxr = px + (mine ? wave : 0) * pout;
     const T *W1 = params + d.off_w1;
 
+    TT(0);
+    const T bias0 = params[d.off_b0 + col];
+    const T biasx = params[d.off_b0 + 16 + (col & 3)];
+    const int lab_g = onehot[(first + row) * no + min(lane, no - 1)];   // needed deep in the chain: fetched now
     // ---- stage: this wave's cube, the conv filters, the output layer ------------------------
     {
         const T *src = cubes + (first + row) * (long)d.cube;
-        T t0[16];   // the first 1024 cube elements fly while the filters are staged
+        T t0[16];   // the first 1024 cube elements and the filters: one memory round trip, before any LDS work
 #pragma unroll
         for (int u = 0; u < 16; u++) t0[u] = src[min(u * 64 + lane, d.cube - 1)];
-        stage_filters_packed<T, FLIP>(params + d.off_w0, rb, tid, nt);
+        constexpr int NWR = (F * K + nt - 1) / nt;
+        T wreg[NWR];
+#pragma unroll
+        for (int u = 0; u < NWR; u++) wreg[u] = params[d.off_w0 + min(u * nt + tid, F * K - 1)];   // clamped, unconditional
+        constexpr int NW2 = (H * OMAX + nt - 1) / nt;
+        T w2r[NW2];
+#pragma unroll
+        for (int u = 0; u < NW2; u++) w2r[u] = params[d.off_w2 + min(u * nt + tid, H * no - 1)];
+        const T b1r = params[d.off_b1 + min(tid, H - 1)], b2r = params[d.off_b2 + min(tid, no - 1)];
+        for (int e = tid; e < WP_LEN; e += nt) rb[e] = 0;
+#pragma unroll
+        for (int u = 0; u < NW2; u++)
+            if (u * nt + tid < H * no) w2s[u * nt + tid] = w2r[u];
+        if (tid < H) b1s[tid] = b1r;
+        if (tid < no) b2s[tid] = b2r;
+        TT(11);
+        lds_barrier();
+        TT(12);
+        // filters as conv_pool_chain wants them (ccnn_device.h: filters 0..15 tap-major, then the
+        // packed tile); the fp32 reference walks the filter backwards in the forward pass only
+        // (gcn_mbgd_fp32.cu:241-243)
+#pragma unroll
+        for (int u = 0; u < NWR; u++) {
+            const int e = u * nt + tid;
+            if (e < F * K) {
+                const int f = e / K, k = e - f * K;
+                const int kk = FLIP ? K - 1 - k : k;
+                if (f < 16) {
+                    rb[kk * LDWK + f] = wreg[u];
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; g++) rb[WL_TILE + (kk + WSTEP * g) * LDWK + 4 * g + (f - 16)] = wreg[u];
+                }
+            }
+        }
+        TT(13);
         for (int e = d.cube + lane; e < L.cube_pad; e += 64) cube[e] = 0;
 #pragma unroll
         for (int u = 0; u < 16; u++) {
@@ -178,28 +235,65 @@ __global__ __launch_bounds__(512) void tile_fwd_bwd(const T *__restrict__ params
                 if (e < d.cube) cube[e] = t[u];
             }
         }
-        for (int e = tid; e < H * no; e += nt) w2s[e] = params[d.off_w2 + e];
-        if (tid < H) b1s[tid] = params[d.off_b1 + tid];
-        if (tid < no) b2s[tid] = params[d.off_b2 + tid];
     }
-    const T bias0 = params[d.off_b0 + col];
-    const T biasx = params[d.off_b0 + 16 + (col & 3)];
-    const int lab_g = onehot[(first + row) * no + min(lane, no - 1)];   // needed deep in the chain: fetched now
-    __syncthreads();
+    lds_barrier();
 
-    // ---- conv + tanh + pool: one wave per sample ----------------------------------------------
-    if (mine) {
-        conv_pool_wave<T>(cube, rb, re, bias0, biasx, lane, [&](int f, int m, T v, int bt) {
-            plr[f * mre + m] = v;
-            pxr[f * mre + m] = (unsigned char)(bt - 2 * m);   // which member of the pair won
-        });
-        wave_sync();
-        const V *sv = reinterpret_cast<const V *>(plr);
-        V *dv = reinterpret_cast<V *>(pool_g + row * pout);
-        for (int o = lane; o < pout / VW; o += 64) dv[o] = sv[o];   // pout = 20 mre: whole 16-byte vectors
+    // FC1 geometry (the product itself comes after the conv phase; its first W1 loads are issued
+    // before it).  Every workgroup reads all of W1: each starts somewhere else (its waves' K ranges
+    // dealt in a rotated order, every range entered at a rotated row), so that at any moment the
+    // workgroups of an XCD pull from different L2 channels instead of queueing on the same lines.
+    constexpr int KQ = nwv >> 1;
+    constexpr int U = sizeof(T) == 4 ? 16 : 4;   // k-steps of W1 per register set, two sets
+    const int T2 = wave & 1, q = ((wave >> 1) + blockIdx.x) & (KQ - 1);
+    const int ks1 = pout >> 2, kper = (ks1 + KQ - 1) / KQ;
+    const int s_lo = q * kper, s_hi = min(s_lo + kper, ks1);
+    const int len = s_hi - s_lo;
+    const int rot = len > 0 ? (int)((blockIdx.x * 5u) % (unsigned)len) : 0;
+    const int ncol = 64 * T2 + 4 * col;
+    const bool nvalid = ncol + 3 < H;
+    const T *wp = W1 + (nvalid ? ncol : 0) + kq * H;
+    struct W1Set {
+        Quad<T> w[U];
+        int ss[U];
+    } fa, fb;
+    auto fc1_issue = [&](int i, W1Set &st) {   // k-steps i .. i + U - 1 of this wave's range (clamped, unconditional)
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            int idx = max(min(i + u, len - 1), 0) + rot;
+            idx = idx >= len ? idx - len : idx;
+            st.ss[u] = min(s_lo + idx, ks1 - 1);
+            st.w[u].load(wp + 4L * st.ss[u] * H);
+        }
+    };
+    fc1_issue(0, fa);
+    fc1_issue(U, fb);
+
+    TT(1);
+    // ---- conv + tanh + pool: the tile's (sample, chain) jobs dealt to the waves ----------------
+    // With a full tile a wave gets the chains of its own sample; with fewer samples than waves a
+    // sample's chains spread over several waves.
+    {
+        const int nc = conv_chains(re);
+        for (int job = wave; job < nb * nc; job += nwv) {
+            const int c = job / nb, s = job - c * nb;
+            T *ps = pl + s * L.pld;
+            unsigned char *pxs = px + s * pout;
+            conv_pool_chain<T>(base + L.cube + s * L.cube_pad, rb, re, c, bias0, biasx, lane, [&](int f, int m, T v, int bt) {
+                ps[f * mre + m] = v;
+                pxs[f * mre + m] = (unsigned char)(bt - 2 * m);   // which member of the pair won
+            });
+        }
     }
-    __syncthreads();
+    lds_barrier();
+    {
+        const int nvr = pout / VW;   // pout = 20 mre: whole 16-byte vectors
+        for (int e = tid; e < nb * nvr; e += nt) {
+            const int s = e / nvr, o = e - s * nvr;
+            reinterpret_cast<V *>(pool_g + (long)(r0 + s) * pout)[o] = reinterpret_cast<const V *>(pl + s * L.pld)[o];
+        }
+    }
 
+    TT(2);
     // ---- FC1: z1[s][n] = sum_p pool[s][p] W1[n + 100 p] ----------------------------------------
     // Rows of the MFMA tile = samples, K = pooled features, split over the waves' K ranges; the
     // columns are neurons in a permuted order so that every lane fetches W1 in 16-byte pieces: wave
@@ -207,30 +301,28 @@ __global__ __launch_bounds__(512) void tile_fwd_bwd(const T *__restrict__ params
     // i.e. one vector load feeds four tiles.  A row of W1 (400 bytes) is fetched exactly once per
     // workgroup: 256 bytes by a T = 0 wave, 144 by its T = 1 partner.
     {
-        const int T2 = wave & 1, q = wave >> 1, KQ = nwv >> 1;
-        const int ks1 = pout >> 2, kper = (ks1 + KQ - 1) / KQ;
-        const int s_lo = q * kper, s_hi = min(s_lo + kper, ks1);
-        const int ncol = 64 * T2 + 4 * col;
-        const bool nvalid = ncol + 3 < H;
-        const T *wp = W1 + (nvalid ? ncol : 0) + kq * H;
         const T *ap = pl + min(col, ms - 1) * L.pld + kq;
         typename Mma<T>::acc_t acc[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[j] = typename Mma<T>::acc_t{0, 0, 0, 0};
-        constexpr int U = sizeof(T) == 4 ? 16 : 8;   // k-steps of W1 in flight
-        for (int s = s_lo; s < s_hi; s += U) {
-            Quad<T> w[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) w[u].load(wp + 4L * min(s + u, s_hi - 1) * H);   // clamped, unconditional
+        auto fc1_mul = [&](int i, const W1Set &st) {
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                if (s + u < s_hi) {
-                    const T a = ap[4 * (s + u)];
+                if (i + u < len) {
+                    const T a = ap[4 * st.ss[u]];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) acc[j] = Mma<T>::mma(a, w[u][j], acc[j]);
+                    for (int j = 0; j < 4; j++) acc[j] = Mma<T>::mma(a, st.w[u][j], acc[j]);
                 }
             }
+        };
+        // sets A and B were issued before the conv phase; each is refilled as soon as it is consumed
+        for (int i = 0; i < len; i += 2 * U) {
+            fc1_mul(i, fa);
+            if (i + 2 * U < len) fc1_issue(i + 2 * U, fa);
+            fc1_mul(i + U, fb);
+            if (i + 3 * U < len) fc1_issue(i + 3 * U, fb);
         }
+        TT(3);
         T *zp = rb;   // [KQ][8][TILE_ZN] (the filters are dead)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -240,7 +332,7 @@ __global__ __launch_bounds__(512) void tile_fwd_bwd(const T *__restrict__ params
                 if (sr < ms && nvalid) zp[(q * 8 + sr) * TILE_ZN + ncol + j] = acc[j][r];
             }
         }
-        __syncthreads();
+        lds_barrier();
         for (int e = tid; e < nb * H; e += nt) {
             const int s = e / H, n = e - s * H;
             T z = 0;
@@ -249,9 +341,10 @@ __global__ __launch_bounds__(512) void tile_fwd_bwd(const T *__restrict__ params
             a1s[s * L.hld + n] = a;
             a1_g[(long)(r0 + s) * H + n] = a;
         }
-        __syncthreads();
+        lds_barrier();
     }
 
+    TT(4);
     // The first W1 rows of the delta-pool product fly during the head (which needs no memory).
     constexpr int NG = (H + 4 * VW - 1) / (4 * VW);   // vectors per lane along n
     const int ntp = (pout + 15) >> 4;                 // 16-feature tiles of the product
@@ -264,10 +357,18 @@ __global__ __launch_bounds__(512) void tile_fwd_bwd(const T *__restrict__ params
             if (n >= H) a[g] = V{};
         }
     };
-    V wa[NG], wb[NG];
-    w1_tile(min(wave, ntp - 1), wa);
-    w1_tile(min(wave + nwv, ntp - 1), wb);
+    // this wave's tiles: wave, wave + nwv, .. in an order that starts at a different tile per workgroup
+    const int prot = (int)((blockIdx.x * 3u) % (unsigned)ntp);
+    auto tile_of = [&](int i) {   // i-th tile slot (may be past the end: clamped, never multiplied)
+        const int t = min(i, ntp - 1) + prot;
+        return t >= ntp ? t - ntp : t;
+    };
+    constexpr int NPF = sizeof(T) == 4 ? 4 : 2;   // tiles in flight per wave
+    V wq[NPF][NG];
+#pragma unroll
+    for (int h = 0; h < NPF; h++) w1_tile(tile_of(wave + h * nwv), wq[h]);
 
+    TT(5);
     // ---- output layer, softmax, loss, delta2, delta1: one wave per sample -----------------------
     if (mine) {
         const T *ar = a1s + wave * L.hld;
@@ -305,8 +406,9 @@ __global__ __launch_bounds__(512) void tile_fwd_bwd(const T *__restrict__ params
             d1_g[row * H + n] = dv;
         }
     }
-    __syncthreads();
+    lds_barrier();
 
+    TT(6);
     // ---- delta at the pooled features: dp[s][p] = (sum_n W1[n + 100 p] d1[s][n]) (1 + pool)(1 - pool) ----
     // Rows of the MFMA tile = 16 pooled features (A = 16 rows of W1), columns = samples (B = rows of
     // d1).  Both operands are contiguous along n, so each lane fetches 16-byte vectors and the
@@ -361,23 +463,21 @@ __global__ __launch_bounds__(512) void tile_fwd_bwd(const T *__restrict__ params
                 }
             }
         };
-        // two tiles ahead: the loads of tile pt + 2 nwv are issued before tile pt is multiplied
-        for (int pt = wave; pt < ntp; pt += 2 * nwv) {
-            V wc[NG];
+        // NPF tiles ahead: a slot's register set is refilled as soon as it has been multiplied, and
+        // has the other slots' products to arrive
+        for (int i = wave; i < ntp; i += NPF * nwv) {
 #pragma unroll
-            for (int g = 0; g < NG; g++) wc[g] = wa[g];
-            w1_tile(min(pt + 2 * nwv, ntp - 1), wa);
-            product(pt, wc);
-            if (pt + nwv < ntp) {
-#pragma unroll
-                for (int g = 0; g < NG; g++) wc[g] = wb[g];
-                w1_tile(min(pt + 3 * nwv, ntp - 1), wb);
-                product(pt + nwv, wc);
+            for (int h = 0; h < NPF; h++) {
+                if (i + h * nwv < ntp) {
+                    product(tile_of(i + h * nwv), wq[h]);
+                    if (i + (h + NPF) * nwv < ntp) w1_tile(tile_of(i + (h + NPF) * nwv), wq[h]);
+                }
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
 
+    TT(7);
     // ---- conv-bias path: per sample and filter, the sum of dp x tanh' over the pooled positions ----
     if (mine) {
         const int f = lane / 3, third = lane - 3 * f;
@@ -387,82 +487,155 @@ __global__ __launch_bounds__(512) void tile_fwd_bwd(const T *__restrict__ params
         const T s1 = __shfl_down(s, 1), s2 = __shfl_down(s, 2);
         if (third == 0 && f < F) bs[wave * 32 + f] = s + s1 + s2;
     }
-    __syncthreads();   // dsm is dead: its region becomes the delta images
+    lds_barrier();   // dsm is dead: its region becomes the delta images
 
-    // ---- bp_maxpooling scatter + conv gradient of this wave's sample ----------------------------
-    // dW0[f][tap] = sum_t delta[f][t] cube[18 t + tap]: A = position-major delta tiles [4 kc][16] (two:
-    // filters 0..15 and 16..31), B = the cube, 11 tap tiles; the delta image covers kc k-steps of
-    // positions at a time (nch chunks) where a whole one would not fit.
-    typename Mma<T>::acc_t c0[11], c1[11];
+    TT(8);
+    // ---- bp_maxpooling scatter + conv gradient of the tile -----------------------------------------
+    // dW0[f][tap] = sum over the tile's samples and positions t of delta[f][t] cube[18 t + tap]:
+    // A = a sample's position-major delta tiles [4 kc][16] (two: filters 0..15 and 16..31), B = its
+    // cube, 11 tap tiles.  Every wave builds the delta image of its own sample; an image covers kc
+    // k-steps of positions at a time (nch chunks) where a whole one would not fit.
+    T *out = part + (long)blockIdx.x * (F * K + F);
+    if (ms > TILE_ACC_MS) {
+        // Full tiles: every wave multiplies its own sample (all 22 products: 22 MFMAs per 13 operand
+        // reads), then the waves' accumulators are added in sample order through LDS, four tap tiles
+        // a round (the round's buffer runs over the delta images into the cubes: both are dead).
+        typename Mma<T>::acc_t c0[11], c1[11];
 #pragma unroll
-    for (int j = 0; j < 11; j++) c0[j] = c1[j] = typename Mma<T>::acc_t{0, 0, 0, 0};
-    if (mine) {
+        for (int j = 0; j < 11; j++) c0[j] = c1[j] = typename Mma<T>::acc_t{0, 0, 0, 0};
+        if (mine) {
+            const int ks = (re + 3) >> 2;
+            T *dl = rb + wave * 2 * L.ldd;
+            for (int ch = 0; ch < nch; ch++) {
+                const int t_lo = 4 * L.kc * ch;
+                const int nks = min(L.kc, ks - L.kc * ch);
+                if (nks <= 0) break;
+                for (int e = lane; e < 2 * L.ldd; e += 64) dl[e] = 0;
+                wave_sync();
+                for (int p = lane; p < pout; p += 64) {
+                    const int f = p / mre, m = p - f * mre;
+                    const int tt = 2 * m + (int)pxr[p] - t_lo;
+                    if (tt >= 0 && tt < 4 * L.kc) dl[(f >> 4) * L.ldd + tt * LDWK + (f & 15)] = plr[p];
+                }
+                wave_sync();
+                const T *ap0 = dl + kq * LDWK + col, *ap1 = ap0 + L.ldd;
+                const T *bp = cube + WSTEP * (t_lo + kq) + col;
+#pragma unroll 2
+                for (int k = 0; k < nks; k++) {
+                    const T a0 = ap0[4 * k * LDWK], a1 = ap1[4 * k * LDWK];
+                    T b[11];
+#pragma unroll
+                    for (int j = 0; j < 11; j++) b[j] = bp[4 * k * WSTEP + 16 * j];
+#pragma unroll
+                    for (int j = 0; j < 11; j++) {
+                        c0[j] = Mma<T>::mma(a0, b[j], c0[j]);
+                        c1[j] = Mma<T>::mma(a1, b[j], c1[j]);
+                    }
+                }
+                wave_sync();   // the image is zeroed again next round
+            }
+        }
+        lds_barrier();
+        TT(9);
+#pragma unroll
+        for (int g = 0; g < 3; g++) {
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                const int j = 4 * g + jj;
+                if (j < 11) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        rb[wave * TILE_RED + (jj * 2 + 0) * 256 + r * 64 + lane] = c0[j][r];
+                        rb[wave * TILE_RED + (jj * 2 + 1) * 256 + r * 64 + lane] = c1[j][r];
+                    }
+                }
+            }
+            lds_barrier();
+            for (int e = tid; e < TILE_RED; e += nt) {
+                const int jj = e >> 9, ft = (e >> 8) & 1, r = (e >> 6) & 3, ln = e & 63;
+                const int j = 4 * g + jj;
+                const int tap = 16 * j + (ln & 15), f = 16 * ft + Mma<T>::row(ln, r);
+                if (j < 11 && tap < K && f < F) {
+                    T s = 0;
+#pragma unroll
+                    for (int w = 0; w < nwv; w++) s = s + rb[w * TILE_RED + e];
+                    out[f * K + tap] = s / re;   // gcn_mbgd_fp64.cu:491
+                }
+            }
+            if (g < 2) lds_barrier();
+        }
+    } else {
+        // Small tiles (fewer samples than waves): the 22 (tap tile, filter tile) products are dealt to
+        // the waves and each wave runs its products over ALL the tile's samples, so the sum over the
+        // samples happens in the accumulators and every wave stores its part of the result itself.
+        constexpr int NJ = (22 + nwv - 1) / nwv;   // products per wave: ids wave, wave + nwv, .. (same filter tile: nwv is even)
+        const int ft = wave & 1;
+        typename Mma<T>::acc_t c[NJ];
+#pragma unroll
+        for (int jj = 0; jj < NJ; jj++) c[jj] = typename Mma<T>::acc_t{0, 0, 0, 0};
+        int joff[NJ];   // cube offset of the j-th product's tap tile (a valid one where the wave has no j-th product)
+#pragma unroll
+        for (int jj = 0; jj < NJ; jj++) joff[jj] = 16 * (wave + jj * nwv < 22 ? (wave + jj * nwv) >> 1 : 0);
         const int ks = (re + 3) >> 2;
         T *dl = rb + wave * 2 * L.ldd;
-        for (int c = 0; c < nch; c++) {
-            const int t_lo = 4 * L.kc * c;
-            const int nks = min(L.kc, ks - L.kc * c);
+        for (int ch = 0; ch < nch; ch++) {
+            const int t_lo = 4 * L.kc * ch;
+            const int nks = min(L.kc, ks - L.kc * ch);
             if (nks <= 0) break;
-            for (int e = lane; e < 2 * L.ldd; e += 64) dl[e] = 0;
-            wave_sync();
-            for (int p = lane; p < pout; p += 64) {
-                const int f = p / mre, m = p - f * mre;
-                const int tt = 2 * m + (int)pxr[p] - t_lo;
-                if (tt >= 0 && tt < 4 * L.kc) dl[(f >> 4) * L.ldd + tt * LDWK + (f & 15)] = plr[p];
-            }
-            wave_sync();
-            const T *ap0 = dl + kq * LDWK + col, *ap1 = ap0 + L.ldd;
-            const T *bp = cube + WSTEP * (t_lo + kq) + col;
-#pragma unroll 2
-            for (int s = 0; s < nks; s++) {
-                const T a0 = ap0[4 * s * LDWK], a1 = ap1[4 * s * LDWK];
-                T b[11];
-#pragma unroll
-                for (int j = 0; j < 11; j++) b[j] = bp[4 * s * WSTEP + 16 * j];
-#pragma unroll
-                for (int j = 0; j < 11; j++) {
-                    c0[j] = Mma<T>::mma(a0, b[j], c0[j]);
-                    c1[j] = Mma<T>::mma(a1, b[j], c1[j]);
+            if (mine) {
+                for (int e = lane; e < 2 * L.ldd; e += 64) dl[e] = 0;
+                wave_sync();
+                for (int p = lane; p < pout; p += 64) {
+                    const int f = p / mre, m = p - f * mre;
+                    const int tt = 2 * m + (int)pxr[p] - t_lo;
+                    if (tt >= 0 && tt < 4 * L.kc) dl[(f >> 4) * L.ldd + tt * LDWK + (f & 15)] = plr[p];
                 }
             }
-            wave_sync();   // the image is zeroed again next round
+            lds_barrier();   // every sample's image is complete
+            for (int sidx = 0; sidx < nb; sidx++) {
+                const T *ap = rb + sidx * 2 * L.ldd + ft * L.ldd + kq * LDWK + col;
+                const T *bp = base + L.cube + sidx * L.cube_pad + WSTEP * (t_lo + kq) + col;
+                for (int k0 = 0; k0 < nks; k0 += 4) {   // operands of four k-steps, then their MFMAs
+                    T a[4], bv[4][NJ];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int kk = min(k0 + u, nks - 1);   // clamped, unconditional
+                        a[u] = ap[4 * kk * LDWK];
+#pragma unroll
+                        for (int jj = 0; jj < NJ; jj++) bv[u][jj] = bp[4 * kk * WSTEP + joff[jj]];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (k0 + u < nks) {
+#pragma unroll
+                            for (int jj = 0; jj < NJ; jj++)
+                                if (wave + jj * nwv < 22) c[jj] = Mma<T>::mma(a[u], bv[u][jj], c[jj]);
+                        }
+                    }
+                }
+            }
+            if (ch + 1 < nch) lds_barrier();   // the images are zeroed again next round
         }
-    }
-    __syncthreads();
-
-    // ---- the tile's conv gradient: the waves' accumulators added in sample order, two tap tiles a round ----
-    T *out = part + (long)blockIdx.x * (F * K + F);
+        TT(9);
 #pragma unroll
-    for (int g = 0; g < 6; g++) {
-#pragma unroll
-        for (int jj = 0; jj < 2; jj++) {
-            const int j = 2 * g + jj;
-            if (j < 11) {
+        for (int jj = 0; jj < NJ; jj++) {
+            const int id = wave + jj * nwv;
+            const int tap = 16 * (id >> 1) + col;
+            if (id < 22 && tap < K) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    rb[wave * TILE_RED + (jj * 2 + 0) * 256 + r * 64 + lane] = c0[j][r];
-                    rb[wave * TILE_RED + (jj * 2 + 1) * 256 + r * 64 + lane] = c1[j][r];
+                    const int f = 16 * ft + Mma<T>::row(lane, r);
+                    if (f < F) out[f * K + tap] = c[jj][r] / re;   // gcn_mbgd_fp64.cu:491
                 }
             }
         }
-        __syncthreads();
-        for (int e = tid; e < TILE_RED; e += nt) {
-            const int jj = e >> 9, ft = (e >> 8) & 1, r = (e >> 6) & 3, ln = e & 63;
-            const int j = 2 * g + jj;
-            const int tap = 16 * j + (ln & 15), f = 16 * ft + Mma<T>::row(ln, r);
-            if (j < 11 && tap < K && f < F) {
-                T s = 0;
-                for (int w = 0; w < nwv; w++) s = s + rb[w * TILE_RED + e];
-                out[f * K + tap] = s / re;   // gcn_mbgd_fp64.cu:491
-            }
-        }
-        __syncthreads();
     }
     if (tid < F) {
         T s = 0;
         for (int w = 0; w < nb; w++) s = s + bs[w * 32 + tid];
         out[F * K + tid] = s / re;
     }
+    TT(10);
 }
 
 template <typename T, bool FLIP>
@@ -471,7 +644,8 @@ int tile_train(const T *params, const T *cubes, const int *onehot, long first, i
                hipStream_t st)
 {
     const bool c13 = d.n_classes == CCNN_CLASSES;
-    auto kern = c13 ? tile_fwd_bwd<T, FLIP, CCNN_CLASSES> : tile_fwd_bwd<T, FLIP, 0>;
+    auto kern = plan.nwv == 8 ? (c13 ? tile_fwd_bwd<T, FLIP, CCNN_CLASSES, 8> : tile_fwd_bwd<T, FLIP, 0, 8>)
+                              : (c13 ? tile_fwd_bwd<T, FLIP, CCNN_CLASSES, 4> : tile_fwd_bwd<T, FLIP, 0, 4>);
     if (int e = allow_smem(kern, plan.smem)) return e;
     launch("tile_fwd_bwd", kern, dim3(plan.tiles), dim3(64 * plan.nwv), plan.smem, st, params, cubes, onehot, first, B,
            plan.ms, plan.nch, d, pool, a1, d1, d2, probs, loss_values, part);

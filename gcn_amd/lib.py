@@ -51,6 +51,7 @@ _SIG = {
     "ccnn_sgd_workspace_bytes": (C.c_size_t, [C.c_int]),
     "ccnn_sgd_f64": (C.c_int, [_P, _P, _P, C.c_long, C.c_long, C.c_int, C.c_double, _P, _P, C.c_size_t, _P]),
     "ccnn_mbgd_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "ccnn_mbgd_path": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "ccnn_mbgd_grad_f32": (C.c_int, [_P, _P, _P, C.c_long, C.c_int, C.c_int, _P, _P, _P, _P, C.c_size_t, _P]),
     "ccnn_mbgd_grad_f64": (C.c_int, [_P, _P, _P, C.c_long, C.c_int, C.c_int, _P, _P, _P, _P, C.c_size_t, _P]),
     "ccnn_mbgd_step_f32": (C.c_int, [_P, _P, _P, C.c_long, C.c_int, C.c_int, C.c_float, _P, _P, C.c_size_t, _P]),

@@ -167,8 +167,14 @@ int ccnn_sgd_f64(double *params, const double *cubes, const int *onehot, long fi
  * gcn_mbgd_fp32.cu:925-1017) -- but with the per-sample gradient slabs already
  * summed over the batch: grad[k] = sum_i slab_i[k] (no lr, no 1/B).
  * loss_values [B] double, as loss_function writes them; probs [B][13] optional.
- * workspace: ccnn_mbgd_workspace_bytes(B, z, elem_size) bytes. */
+ * workspace: ccnn_mbgd_workspace_bytes(B, z, elem_size) bytes.
+ * ccnn_mbgd_path: which implementation a batch of B takes (the results are the same to the
+ * tolerances above; the choice is by speed): 0 = one workgroup per sample (the reference's
+ * batch sizes), 1 = one workgroup per tile of up to eight samples (large batches), 2 = one launch
+ * per layer (large batches of shapes whose tile does not fit the LDS); negative: invalid
+ * arguments.  The environment variable CCNN_MBGD_PATH=fused|tile|layers overrides it. */
 size_t ccnn_mbgd_workspace_bytes(int B, int z, int elem_size);
+int ccnn_mbgd_path(int B, int z, int elem_size);
 int ccnn_mbgd_grad_f32(const float *params, const float *cubes, const int *onehot, long first,
                        int B, int z, float *grad, double *loss_values, float *probs,
                        void *workspace, size_t workspace_bytes, void *stream);
