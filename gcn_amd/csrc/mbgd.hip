@@ -532,11 +532,7 @@ __device__ __forceinline__ T colsum8(int B, int rg, int c, T *red, Term term)
 // raises its flag there, waits for the same workgroup of every rank and adds the world
 // contributions in rank order before `upd` sees them (comm.h).  No grid-wide barrier: a
 // workgroup only depends on its namesakes on the other ranks.
-//
-// gridDim.y > 1 (large batches): split y sums only rows [y Bs, (y+1) Bs) of the batch (and of the
-// conv-gradient slab's few rows all go to split 0) and stores its sums in grad + y * grad_stride;
-// apply_partials then adds the splits in order.  A single 2048-row sum per thread would be 16
-// dependent rounds of loads.
+// Batches of more than 256 samples take grad_reduce_big below instead.
 template <typename T, int KF, int NO>
 __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int off_w1, int off_b1,
                                                           int off_w2, int off_b2,
@@ -546,26 +542,13 @@ __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int o
                                                           const T *__restrict__ d2,
                                                           const T *__restrict__ slab, int slab_rows, int nb_w1,
                                                           int nb_w0, int nb_w2, T *__restrict__ grad,
-                                                          long grad_stride, UpdateRule<T> upd, CommDev xc,
+                                                          UpdateRule<T> upd, CommDev xc,
                                                           unsigned xstep)
 {
     __shared__ T red[8 * 64];
     const int tid = threadIdx.x;
     const int no = NO ? NO : (off_b2 - off_w2) / H;   // classes: W2 is [100 x classes]; NO as in sample_fwd_bwd
     int blk = blockIdx.x;
-    if (gridDim.y > 1) {
-        const int y = blockIdx.y, ny = gridDim.y;
-        const int bs = (B + ny - 1) / ny, b_lo = min(y * bs, B);
-        pool += (long)b_lo * pout;
-        a1 += (long)b_lo * H;
-        d1 += (long)b_lo * H;
-        d2 += (long)b_lo * no;
-        B = min(bs, B - b_lo);
-        // the conv-gradient rows are few (one per workgroup of conv_bwd_batch): split 0 sums them
-        // all and the other splits' workgroups for those columns have nothing to do
-        if (y > 0 && blk >= nb_w1 && blk < nb_w1 + nb_w0) return;
-        grad += y * grad_stride;
-    }
     int ok[4] = {-1, -1, -1, -1};   // parameter index of this thread's outputs (-1: none)
     T og[4] = {0, 0, 0, 0};         // and their batch sums
     if (blk < nb_w1) {
@@ -751,8 +734,7 @@ __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int o
 //   conv_pool_fwd<TRAIN> + fc_head_fwd<TRAIN>   forward, loss, delta2, delta1        (forward.hip)
 //   dpool_bwd        dpool = (delta1 W1^T)(1 + pool)(1 - pool): one [B x 100] x [100 x Pout] product
 //   conv_bwd_batch   bp_maxpooling scatter + conv gradient, accumulated over a workgroup's samples
-//   grad_reduce      dW1 = pool^T delta1, dW2, db1, db2, and the column sums of conv_bwd_batch's partials
-//   apply_partials   adds grad_reduce's batch splits in order and applies the update
+//   grad_reduce_big  dW1 = pool^T delta1, dW2, db1, db2, the column sums of conv_bwd_batch's partials, the update
 // W1 is read once per 16-row tile of the products instead of twice per sample.
 
 // dpool[b][p] = (sum_n W1[n + 100 p] d1[b][n]) (1 + pool[b][p]) (1 - pool[b][p])
@@ -994,18 +976,116 @@ __global__ __launch_bounds__(CB_THREADS) void conv_bwd_batch(const T *__restrict
     if (wave == 0 && lane < F) out[F * K + lane] = bsum / re;
 }
 
-// w -= lr * (sum over the S batch splits, in order) [/ divisor], or grad = that sum.
-// Entries below single_hi (the conv weights and bias) have one partial only: split 0's.
-template <typename T>
-__global__ void apply_partials(const T *__restrict__ part, int S, long stride, int n, int single_hi, T *__restrict__ grad,
-                               UpdateRule<T> upd)
+// Batch sums for large batches in ONE pass (grad_reduce above gives a thread all B rows of its
+// output: a 2048-row sum would be 16 dependent rounds of loads).  Here the batch is split over the
+// waves of a workgroup instead and the partial sums meet in LDS:
+//   7 x nb_w1 workgroups   one 16 x 16 tile of dW1 = pool^T d1 each (p tile, neuron tile); wave w
+//                          multiplies rows [w bs, (w+1) bs) of the batch, the eight accumulators
+//                          are added in wave order
+//   nb_w0 workgroups       64 columns x 8 row groups of the conv-gradient partials (few rows)
+//   then 16 columns x 32 row groups: dW2[o + classes n] = sum_b a1[b][n] d2[b][o], db1, db2
+// Every output is final, so the update (or the store of the summed gradient) happens here.
+constexpr int GB_THREADS = 512;
+template <typename T, int NO>
+__global__ __launch_bounds__(GB_THREADS) void grad_reduce_big(int B, int pout, int off_w1, int off_b1, int off_w2,
+                                                              int off_b2, const T *__restrict__ pool,
+                                                              const T *__restrict__ a1, const T *__restrict__ d1,
+                                                              const T *__restrict__ d2, const T *__restrict__ slab,
+                                                              int slab_rows, int nb_w1, int nb_w0, int nb_w2,
+                                                              int nb_b1, T *__restrict__ grad, UpdateRule<T> upd)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    T tot = 0;
-    const int ns = k < single_hi ? 1 : S;
-    for (int s = 0; s < ns; s++) tot = tot + part[s * stride + k];
-    upd.apply(grad, k, tot);
+    __shared__ T red[8 * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int no = NO ? NO : (off_b2 - off_w2) / H;
+    int blk = blockIdx.x;
+    if (blk < 7 * nb_w1) {
+        const int pt = blk / 7, ntile = blk - 7 * pt;
+        const int col = lane & 15, kq = lane >> 4;
+        const int p0 = pt * 16, n0 = ntile * 16;
+        const int bs = ((B + 7) / 8 + 3) & ~3;   // rows per wave: whole k-steps
+        const int b_lo = min(wave * bs, B), len = min(b_lo + bs, B) - b_lo;
+        const bool pv = p0 + col < pout, nv = n0 + col < H;
+        typename Mma<T>::acc_t acc = {0, 0, 0, 0};
+        if (len > 0) {
+            const T *ap = pool + (long)b_lo * pout + min(p0 + col, pout - 1);   // clamped: loads stay in bounds, masked below
+            const T *bp = d1 + (long)b_lo * H + min(n0 + col, H - 1);
+            const int ks = (len + 3) >> 2;
+            constexpr int KF = sizeof(T) == 4 ? 32 : 16;   // k-steps of operands in flight
+            for (int s = 0; s < ks; s += KF) {
+                T a[KF], w[KF];
+#pragma unroll
+                for (int u = 0; u < KF; u++) {
+                    const int b = min(4 * (s + u) + kq, len - 1);
+                    a[u] = ap[(long)b * pout];
+                    w[u] = bp[(long)b * H];
+                }
+#pragma unroll
+                for (int u = 0; u < KF; u++) {
+                    const bool bv = 4 * (s + u) + kq < len;
+                    acc = Mma<T>::mma((bv && pv) ? a[u] : T(0), (bv && nv) ? w[u] : T(0), acc);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[wave * 256 + r * 64 + lane] = acc[r];
+        __syncthreads();
+        if (tid < 256) {
+            const int r = tid >> 6, ln = tid & 63;
+            T tot = 0;
+#pragma unroll
+            for (int w = 0; w < 8; w++) tot = tot + red[w * 256 + tid];
+            const int p = p0 + Mma<T>::row(ln, r), n = n0 + (ln & 15);
+            if (p < pout && n < H) upd.apply(grad, off_w1 + n + H * p, tot);
+        }
+        return;
+    }
+    blk -= 7 * nb_w1;
+    if (blk < nb_w0) {
+        const int c = tid & 63, rg = tid >> 6;
+        const int k = min(blk * 64 + c, F * K + F - 1);
+        const T tot = colsum8<T>(slab_rows, rg, c, red, [&](int b) { return slab[(long)b * (F * K + F) + k]; });
+        if (rg == 0 && blk * 64 + c < F * K + F) upd.apply(grad, k, tot);   // partial layout = W0 | b0 = params[0..)
+        return;
+    }
+    blk -= nb_w0;
+    const int c = tid & 15, rg = tid >> 4;   // 16 columns x 32 row groups
+    auto colsum32 = [&](auto term) {
+        T acc = 0;
+        for (int b0 = rg; b0 < B; b0 += 32 * 16) {
+            T v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const int b = b0 + 32 * u;
+                const T x = term(min(b, B - 1));   // clamped load, masked value
+                v[u] = b < B ? x : T(0);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; u++) acc = acc + v[u];
+        }
+        red[rg * 16 + c] = acc;
+        __syncthreads();
+        T tot = 0;
+        if (rg == 0) {
+#pragma unroll
+            for (int r = 0; r < 32; r++) tot = tot + red[r * 16 + c];
+        }
+        return tot;
+    };
+    if (blk < nb_w2) {
+        const int k = min(blk * 16 + c, H * no - 1);   // k = o + classes * n
+        const int nn = k / no, o = k - nn * no;
+        const T tot = colsum32([&](int b) { return a1[(long)b * H + nn] * d2[(long)b * no + o]; });
+        if (rg == 0 && blk * 16 + c < H * no) upd.apply(grad, off_w2 + k, tot);
+    } else if (blk < nb_w2 + nb_b1) {
+        const int q = blk - nb_w2;
+        const int n = min(q * 16 + c, H - 1);
+        const T tot = colsum32([&](int b) { return d1[(long)b * H + n]; });
+        if (rg == 0 && q * 16 + c < H) upd.apply(grad, off_b1 + n, tot);
+    } else {
+        const int o = min(c, no - 1);
+        const T tot = colsum32([&](int b) { return d2[(long)b * no + o]; });
+        if (rg == 0 && c < no) upd.apply(grad, off_b2 + o, tot);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1017,10 +1097,9 @@ __global__ void apply_partials(const T *__restrict__ part, int S, long stride, i
 constexpr int BATCHED_MIN_B = 768;
 constexpr int TILE_MIN_B = 576;             // from here the sample-tile kernel (tile.hip) takes the per-sample part
 constexpr int BATCHED_MAX_PARTIALS = 256;   // workgroups (= partial gradient rows) of conv_bwd_batch
-constexpr int BATCHED_SPLIT_ROWS = 256;     // rows of the batch one grad_reduce split sums
-constexpr int BATCHED_MAX_SPLITS = 16;
-// FUSED: sample_fwd_bwd + grad_reduce.  TILE: tile_fwd_bwd + grad_reduce (+ apply_partials).
-// LAYERS: the five layer kernels + grad_reduce + apply_partials (shapes whose tile does not fit the LDS).
+constexpr int BATCHED_SPLIT_ROWS = 256;     // up to here one thread of grad_reduce sums all rows of the batch
+// FUSED: sample_fwd_bwd + grad_reduce.  TILE: tile_fwd_bwd + grad_reduce / grad_reduce_big.
+// LAYERS: the four layer kernels + grad_reduce / grad_reduce_big (shapes whose tile does not fit the LDS).
 // CCNN_MBGD_PATH=fused|batched|tile|layers overrides the choice by batch size (tests run every
 // path on the same inputs; "batched" = whatever a large batch would take).
 enum class StepPath { FUSED, TILE, LAYERS };
@@ -1067,17 +1146,11 @@ inline bool split_samples(int B)
     if (forced >= 0) return forced != 0;
     return 16 * ((B + 7) / 8) <= fb_cus();
 }
-inline int batched_splits(int B)
-{
-    const int s = (B + BATCHED_SPLIT_ROWS - 1) / BATCHED_SPLIT_ROWS;
-    return s < 1 ? 1 : s > BATCHED_MAX_SPLITS ? BATCHED_MAX_SPLITS : s;
-}
-
 template <typename T>
 struct MbgdWs {
     T *pool, *a1, *d1, *d2, *slab, *probs;
     // batched path only
-    T *dp, *parts, *gsum;
+    T *dp, *gsum;
     unsigned char *px;
     int *ctr;
     StepPath path;
@@ -1103,7 +1176,6 @@ struct MbgdWs {
                 b += align_up((size_t)B * d.pout * sizeof(T));      // dpool
                 b += align_up((size_t)B * d.pout);                  // pool winners, one byte each
             }
-            b += align_up((size_t)batched_splits(B) * d.nparams * sizeof(T));   // grad_reduce's batch splits
             b += align_up((size_t)d.nparams * sizeof(T));           // summed gradient (multi-GPU exchange)
             b += align_up(TRAIN_CTR_INTS * sizeof(int));
         }
@@ -1117,7 +1189,7 @@ struct MbgdWs {
         d1 = c.take<T>((size_t)B * H);
         d2 = c.take<T>((size_t)B * d.n_classes);
         probs = c.take<T>((size_t)B * d.n_classes);
-        dp = parts = gsum = nullptr;
+        dp = gsum = nullptr;
         px = nullptr;
         ctr = nullptr;
         path = step_path<T>(B, d, &plan);
@@ -1130,7 +1202,6 @@ struct MbgdWs {
                 dp = c.take<T>((size_t)B * d.pout);
                 px = c.take<unsigned char>((size_t)B * d.pout);
             }
-            parts = c.take<T>((size_t)batched_splits(B) * d.nparams);
             gsum = c.take<T>((size_t)d.nparams);
             ctr = c.take<int>(TRAIN_CTR_INTS);
         }
@@ -1154,8 +1225,8 @@ int exchange_update<double>(ccnn_comm *cm, double *params, const double *grad, c
 
 // The two launches every path ends with share this: batch sums (+ update / exchange).
 template <typename T>
-int launch_grad_reduce(int B, const ccnn_dims_t &d, const MbgdWs<T> &w, int slab_rows, int splits, T *grad,
-                       long grad_stride, UpdateRule<T> upd, ccnn_comm *cm, hipStream_t st)
+int launch_grad_reduce(int B, const ccnn_dims_t &d, const MbgdWs<T> &w, int slab_rows, T *grad, UpdateRule<T> upd,
+                       ccnn_comm *cm, hipStream_t st)
 {
     const int nb_w1 = (d.pout + 15) / 16;
     const int nb_w0 = (F * K + F + 63) / 64;
@@ -1188,9 +1259,9 @@ int launch_grad_reduce(int B, const ccnn_dims_t &d, const MbgdWs<T> &w, int slab
     launch("grad_reduce",
            narrow ? (c13 ? grad_reduce<T, 16, CCNN_CLASSES> : grad_reduce<T, 16, 0>)
                   : (c13 ? grad_reduce<T, 32, CCNN_CLASSES> : grad_reduce<T, 32, 0>),
-           dim3(nblocks, splits), dim3(GR_THREADS), 0, st,
+           dim3(nblocks), dim3(GR_THREADS), 0, st,
            B, d.pout, d.off_w1, d.off_b1, d.off_w2, d.off_b2, w.pool, w.a1, w.d1, w.d2, w.slab, slab_rows, nb_w1, nb_w0,
-           nb_w2, grad, grad_stride, upd, xc, xstep);
+           nb_w2, grad, upd, xc, xstep);
     CCNN_LAUNCH_CHECK();
     return 0;
 }
@@ -1228,16 +1299,19 @@ int mbgd_batched(const T *params, const T *cubes, const int *onehot, long first,
         CCNN_LAUNCH_CHECK();
     }
     }
-    const int S = batched_splits(B);
-    if (S == 1) return launch_grad_reduce<T>(B, d, w, G, 1, grad, 0, upd, cm, st);
-    // splits: partial sums first, then one pass that adds them in order and updates (or, across
-    // GPUs, stores the sum for the exchange + update kernel)
-    if (int e = launch_grad_reduce<T>(B, d, w, G, S, w.parts, d.nparams, UpdateRule<T>{}, nullptr, st)) return e;
-    T *out = cm ? w.gsum : grad;
-    UpdateRule<T> rule = cm ? UpdateRule<T>{} : upd;
-    launch("apply_partials", apply_partials<T>, dim3((d.nparams + 255) / 256), dim3(256), 0, st, (const T *)w.parts, S,
-           (long)d.nparams, d.nparams, d.off_w1, out, rule);
-    CCNN_LAUNCH_CHECK();
+    if (B <= BATCHED_SPLIT_ROWS) return launch_grad_reduce<T>(B, d, w, G, grad, upd, cm, st);
+    // large batches: the batch is split inside the workgroups of one launch; across GPUs it stores
+    // the sum for the exchange + update kernel
+    {
+        const int nb_w1 = (d.pout + 15) / 16, nb_w0 = (F * K + F + 63) / 64;
+        const int nb_w2 = (H * d.n_classes + 15) / 16, nb_b1 = (H + 15) / 16;
+        const bool c13 = d.n_classes == CCNN_CLASSES;
+        launch("grad_reduce_big", c13 ? grad_reduce_big<T, CCNN_CLASSES> : grad_reduce_big<T, 0>,
+               dim3(7 * nb_w1 + nb_w0 + nb_w2 + nb_b1 + 1), dim3(GB_THREADS), 0, st, B, d.pout, d.off_w1, d.off_b1,
+               d.off_w2, d.off_b2, (const T *)w.pool, (const T *)w.a1, (const T *)w.d1, (const T *)w.d2,
+               (const T *)w.slab, G, nb_w1, nb_w0, nb_w2, nb_b1, cm ? w.gsum : grad, cm ? UpdateRule<T>{} : upd);
+        CCNN_LAUNCH_CHECK();
+    }
     if (cm) {
         if (!upd.params) return CCNN_E_INVALID;
         return exchange_update<T>(cm, upd.params, w.gsum, upd, z, d.nparams, st);
@@ -1273,7 +1347,7 @@ int mbgd_impl(const T *params, const T *cubes, const int *onehot, long first, in
                onehot, first, d, w.pool, w.a1, w.d1, w.d2, probs, loss_values, w.slab, B);
     }
     CCNN_LAUNCH_CHECK();
-    return launch_grad_reduce<T>(B, d, w, B, 1, grad, 0, upd, cm, st);
+    return launch_grad_reduce<T>(B, d, w, B, grad, upd, cm, st);
 }
 
 }  // namespace ccnn
