@@ -1091,11 +1091,13 @@ __global__ __launch_bounds__(GB_THREADS) void grad_reduce_big(int B, int pout, i
 // ---------------------------------------------------------------------------
 // Which path a batch of B takes.  The fused per-sample kernel is a chain of latency-bound phases
 // that costs the same from 1 to 256 samples (one workgroup per CU) and then grows by the full
-// chain per 256 samples; the batched kernels have a floor twice as high and grow a quarter as
-// fast.  Measured crossovers: B = 640 (z = 103, fp32), 800 (z = 200, fp32), 580 (z = 176, fp64).
-// CCNN_MBGD_PATH=fused|batched overrides (tests run both on the same inputs).
-constexpr int BATCHED_MIN_B = 768;
-constexpr int TILE_MIN_B = 576;             // from here the sample-tile kernel (tile.hip) takes the per-sample part
+// chain per 256 samples (every workgroup walks all of W1 twice).  The sample-tile kernel's chain is
+// half as long again for one sample but takes up to eight samples per workgroup at little more, and
+// reads W1 twice per TILE.  Measured crossovers fused -> tile: B = 450 (z = 103, fp32), 650
+// (z = 200, fp32), 480 (z = 176, fp64).  Where a tile holds so few samples that the batch needs
+// more than one round of workgroups (fp64 at large band counts: the LDS holds four samples) the
+// layer kernels win again from about 2000 samples (z = 176, fp64: 180 against 220 us at 2048).
+constexpr int BATCHED_MIN_B = 768;          // fused -> layer kernels where no tile fits
 constexpr int BATCHED_MAX_PARTIALS = 256;   // workgroups (= partial gradient rows) of conv_bwd_batch
 constexpr int BATCHED_SPLIT_ROWS = 256;     // up to here one thread of grad_reduce sums all rows of the batch
 // FUSED: sample_fwd_bwd + grad_reduce.  TILE: tile_fwd_bwd + grad_reduce / grad_reduce_big.
@@ -1106,7 +1108,7 @@ enum class StepPath { FUSED, TILE, LAYERS };
 template <typename T>
 inline StepPath step_path(int B, const ccnn_dims_t &d, TilePlan *plan)
 {
-    TilePlan tp;
+    TilePlan tp = {};
     const bool fits = tile_plan<T>(B, d, &tp);
     if (plan && fits) *plan = tp;
     if (const char *e = getenv("CCNN_MBGD_PATH")) {
@@ -1114,7 +1116,9 @@ inline StepPath step_path(int B, const ccnn_dims_t &d, TilePlan *plan)
         if (!strcmp(e, "layers")) return StepPath::LAYERS;
         if (!strcmp(e, "batched") || !strcmp(e, "tile")) return fits ? StepPath::TILE : StepPath::LAYERS;
     }
-    if (fits && B >= TILE_MIN_B) return StepPath::TILE;
+    const int tile_min_b = (sizeof(T) == 8 || d.z <= 128) ? 512 : 704;
+    const bool one_round = tp.tiles <= 256;
+    if (fits && B >= tile_min_b && (one_round || sizeof(T) == 4)) return StepPath::TILE;
     return B >= BATCHED_MIN_B ? StepPath::LAYERS : StepPath::FUSED;
 }
 // Two workgroups per sample in the fused kernel: while both halves of every sample fit the device

@@ -201,7 +201,9 @@ int ccnn_mbgd_step_f64(double *params, const double *cubes, const int *onehot, l
  * each other live in a fixed device array inside the library, CCNN_NOALLOC_SCRATCH_BYTES
  * per GPU, held until the process ends; a batch whose rows
  * (ccnn_mbgd_workspace_bytes(B, z, 4)) do not fit is rejected with CCNN_E_SCRATCH: 8 MiB
- * holds B = 513 at z = 103, 457 at z = 200, 359 at z = 448.  The call makes no hipMalloc /
+ * holds every B up to 1904 at z = 103, up to 457 at z = 200, up to 359 at z = 448 (larger
+ * batches that take the sample-tile path keep fewer rows and can fit again, e.g. 704..996 at
+ * z = 200: the size function tells).  The call makes no hipMalloc /
  * hipFree and uses no allocating library routine (keep ccnn_profile_enable off: the timing
  * hooks create events).  Results are bit-identical to ccnn_mbgd_step_f32.  All calls on one
  * GPU share that GPU's array: calls that overlap in time on one GPU (two streams, two
