@@ -44,6 +44,7 @@ def kernel_work(d, z):
         "tile_fwd_bwd": ("mfma", 2 * conv + 2 * fc1 + 4.0 * 1300),
         # dW1 = pool^T d1, dW2 = a1^T d2
         "grad_reduce": ("mfma", fc1 + 2.0 * 1300),
+        "grad_reduce_big": ("mfma", fc1 + 2.0 * 1300),
         "conv_pool_fwd": ("mfma", conv),
         "fc_head_fwd": ("mfma", fc1 + 2.0 * 1300),
         # the batched training path: conv fwd | FC1 + FC2 fwd + delta1 | delta at the pooled features | conv gradient
@@ -51,8 +52,6 @@ def kernel_work(d, z):
         "fc_head_fwd_train": ("mfma", fc1 + 4.0 * 1300),
         "dpool_bwd": ("mfma", fc1),
         "conv_bwd_batch": ("mfma", conv),
-        # per launch: the batch splits read, the parameters read and written
-        "apply_partials": ("hbm", None),
         # 9z values read + 9z written + 9 int32 indices
         "gather_tile": ("hbm", 2.0 * 9 * z * 4 + 36),
         # per launch: read params, read gradient, write params
@@ -75,7 +74,7 @@ def committed_traffic(workload, batch, kernel):
     return None
 
 
-def kernel_rows(rep, d, z, pixels, passes=None, world=1, splits=1):
+def kernel_rows(rep, d, z, pixels, passes=None, world=1):
     """Per-kernel table from the library's event timings: average duration, achieved rate on the
     kernel's algorithmic work and its fraction of the peak that bounds it."""
     work = kernel_work(d, z)
@@ -85,7 +84,7 @@ def kernel_rows(rep, d, z, pixels, passes=None, world=1, splits=1):
             continue
         bound, per_px = work[name]
         if per_px is None:
-            factor = {"allreduce_apply": 3.0 + 2.0 * world, "apply_partials": 2.0 + splits}.get(name, 3.0)
+            factor = {"allreduce_apply": 3.0 + 2.0 * world}.get(name, 3.0)
             units = factor * d.nparams * 4 * cnt
         else:
             # a pass over n pixels may be several launches (the library works through its workspace in chunks)
@@ -100,8 +99,8 @@ def kernel_rows(rep, d, z, pixels, passes=None, world=1, splits=1):
     return rows
 
 
-TRAIN_KERNELS = ("sample_fwd_bwd", "tile_fwd_bwd", "grad_reduce", "update_f32_kernel", "allreduce_apply", "conv_pool_fwd_train",
-                 "fc_head_fwd_train", "dpool_bwd", "conv_bwd_batch", "apply_partials")
+TRAIN_KERNELS = ("sample_fwd_bwd", "tile_fwd_bwd", "grad_reduce", "grad_reduce_big", "update_f32_kernel", "allreduce_apply", "conv_pool_fwd_train",
+                 "fc_head_fwd_train", "dpool_bwd", "conv_bwd_batch")
 STEP_PATHS = {0: "fused per-sample kernel", 1: "sample-tile kernel", 2: "batched layer kernels"}   # ccnn_mbgd_path
 
 
@@ -153,8 +152,7 @@ def train_rate(params_h, cubes, onehot_d, z, B, steps, workload, profile=True):
             step(i)
         torch.cuda.synchronize()
         L.profile_enable(False)
-        rows = kernel_rows(L.profile_report(), d, z, {k: B for k in TRAIN_KERNELS},
-                           splits=min(16, max(1, (B + 255) // 256)))
+        rows = kernel_rows(L.profile_report(), d, z, {k: B for k in TRAIN_KERNELS})
         out["roofline"] = dominant(rows, workload, B)
         out["kernels"] = {k: {"avg_us": v["avg_us"], "frac": v["frac"]} for k, v in rows.items()}
     return out

@@ -979,7 +979,8 @@ __global__ __launch_bounds__(CB_THREADS) void conv_bwd_batch(const T *__restrict
 // Batch sums for large batches in ONE pass (grad_reduce above gives a thread all B rows of its
 // output: a 2048-row sum would be 16 dependent rounds of loads).  Here the batch is split over the
 // waves of a workgroup instead and the partial sums meet in LDS:
-//   7 x nb_w1 workgroups   one 16 x 16 tile of dW1 = pool^T d1 each (p tile, neuron tile); wave w
+//   7 x nb_w1 workgroups   (nb_w1 = p tiles rounded up to a multiple of eight)
+//                          one 16 x 16 tile of dW1 = pool^T d1 each (p tile, neuron tile); wave w
 //                          multiplies rows [w bs, (w+1) bs) of the batch, the eight accumulators
 //                          are added in wave order
 //   nb_w0 workgroups       64 columns x 8 row groups of the conv-gradient partials (few rows)
@@ -999,7 +1000,11 @@ __global__ __launch_bounds__(GB_THREADS) void grad_reduce_big(int B, int pout, i
     const int no = NO ? NO : (off_b2 - off_w2) / H;
     int blk = blockIdx.x;
     if (blk < 7 * nb_w1) {
-        const int pt = blk / 7, ntile = blk - 7 * pt;
+        // the seven neuron tiles of one p tile run on ONE XCD (workgroup b lands on XCD b mod 8), so a
+        // slice of pool is fetched from memory into one L2 instead of into seven
+        const int xcd = blk & 7, i = blk >> 3;
+        const int pt = 8 * (i / 7) + xcd, ntile = i % 7;
+        if (pt * 16 >= pout) return;   // the grid is rounded up to whole groups of eight p tiles
         const int col = lane & 15, kq = lane >> 4;
         const int p0 = pt * 16, n0 = ntile * 16;
         const int bs = ((B + 7) / 8 + 3) & ~3;   // rows per wave: whole k-steps
@@ -1095,8 +1100,8 @@ __global__ __launch_bounds__(GB_THREADS) void grad_reduce_big(int B, int pout, i
 // half as long again for one sample but takes up to eight samples per workgroup at little more, and
 // reads W1 twice per TILE.  Measured crossovers fused -> tile: B = 450 (z = 103, fp32), 650
 // (z = 200, fp32), 480 (z = 176, fp64).  Where a tile holds so few samples that the batch needs
-// more than one round of workgroups (fp64 at large band counts: the LDS holds four samples) the
-// layer kernels win again from about 2000 samples (z = 176, fp64: 180 against 220 us at 2048).
+// more than one round of workgroups (fp64, or fp32 beyond 200 bands: the LDS holds four samples)
+// the layer kernels win again from about 2000 samples (z = 176, fp64: 180 against 220 us at 2048).
 constexpr int BATCHED_MIN_B = 768;          // fused -> layer kernels where no tile fits
 constexpr int BATCHED_MAX_PARTIALS = 256;   // workgroups (= partial gradient rows) of conv_bwd_batch
 constexpr int BATCHED_SPLIT_ROWS = 256;     // up to here one thread of grad_reduce sums all rows of the batch
@@ -1117,8 +1122,10 @@ inline StepPath step_path(int B, const ccnn_dims_t &d, TilePlan *plan)
         if (!strcmp(e, "batched") || !strcmp(e, "tile")) return fits ? StepPath::TILE : StepPath::LAYERS;
     }
     const int tile_min_b = (sizeof(T) == 8 || d.z <= 128) ? 512 : 704;
-    const bool one_round = tp.tiles <= 256;
-    if (fits && B >= tile_min_b && (one_round || sizeof(T) == 4)) return StepPath::TILE;
+    // one round of workgroups, or several rounds of FULL tiles (z = 224, fp32, B = 2048: tiles of
+    // four samples in two rounds take 197 us where the layer kernels take 129)
+    const bool rounds_ok = tp.tiles <= 256 || (sizeof(T) == 4 && tp.ms == 8);
+    if (fits && B >= tile_min_b && rounds_ok) return StepPath::TILE;
     return B >= BATCHED_MIN_B ? StepPath::LAYERS : StepPath::FUSED;
 }
 // Two workgroups per sample in the fused kernel: while both halves of every sample fit the device
@@ -1307,7 +1314,7 @@ int mbgd_batched(const T *params, const T *cubes, const int *onehot, long first,
     // large batches: the batch is split inside the workgroups of one launch; across GPUs it stores
     // the sum for the exchange + update kernel
     {
-        const int nb_w1 = (d.pout + 15) / 16, nb_w0 = (F * K + F + 63) / 64;
+        const int nb_w1 = ((d.pout + 15) / 16 + 7) & ~7, nb_w0 = (F * K + F + 63) / 64;   // p tiles in whole groups of eight
         const int nb_w2 = (H * d.n_classes + 15) / 16, nb_b1 = (H + 15) / 16;
         const bool c13 = d.n_classes == CCNN_CLASSES;
         launch("grad_reduce_big", c13 ? grad_reduce_big<T, CCNN_CLASSES> : grad_reduce_big<T, 0>,

@@ -239,31 +239,24 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
     lds_barrier();
 
     // FC1 geometry (the product itself comes after the conv phase; its first W1 loads are issued
-    // before it).  Every workgroup reads all of W1: each starts somewhere else (its waves' K ranges
-    // dealt in a rotated order, every range entered at a rotated row), so that at any moment the
-    // workgroups of an XCD pull from different L2 channels instead of queueing on the same lines.
+    // before it).  Every workgroup reads all of W1: its waves' K ranges are dealt in an order rotated
+    // by the workgroup number, so that at any moment the workgroups of an XCD pull from different
+    // L2 channels instead of queueing on the same lines.
     constexpr int KQ = nwv >> 1;
     constexpr int U = sizeof(T) == 4 ? 16 : 4;   // k-steps of W1 per register set, two sets
     const int T2 = wave & 1, q = ((wave >> 1) + blockIdx.x) & (KQ - 1);
     const int ks1 = pout >> 2, kper = (ks1 + KQ - 1) / KQ;
     const int s_lo = q * kper, s_hi = min(s_lo + kper, ks1);
     const int len = s_hi - s_lo;
-    const int rot = len > 0 ? (int)((blockIdx.x * 5u) % (unsigned)len) : 0;
     const int ncol = 64 * T2 + 4 * col;
     const bool nvalid = ncol + 3 < H;
-    const T *wp = W1 + (nvalid ? ncol : 0) + kq * H;
+    const T *wp = W1 + (nvalid ? ncol : 0) + (4L * min(s_lo, ks1 - 1) + kq) * H;   // (an empty range still loads from valid rows)
     struct W1Set {
         Quad<T> w[U];
-        int ss[U];
     } fa, fb;
     auto fc1_issue = [&](int i, W1Set &st) {   // k-steps i .. i + U - 1 of this wave's range (clamped, unconditional)
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            int idx = max(min(i + u, len - 1), 0) + rot;
-            idx = idx >= len ? idx - len : idx;
-            st.ss[u] = min(s_lo + idx, ks1 - 1);
-            st.w[u].load(wp + 4L * st.ss[u] * H);
-        }
+        for (int u = 0; u < U; u++) st.w[u].load(wp + 4 * H * max(min(i + u, len - 1), 0));
     };
     fc1_issue(0, fa);
     fc1_issue(U, fb);
@@ -301,7 +294,7 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
     // i.e. one vector load feeds four tiles.  A row of W1 (400 bytes) is fetched exactly once per
     // workgroup: 256 bytes by a T = 0 wave, 144 by its T = 1 partner.
     {
-        const T *ap = pl + min(col, ms - 1) * L.pld + kq;
+        const T *ap = pl + min(col, ms - 1) * L.pld + 4 * s_lo + kq;
         typename Mma<T>::acc_t acc[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[j] = typename Mma<T>::acc_t{0, 0, 0, 0};
@@ -309,7 +302,7 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 if (i + u < len) {
-                    const T a = ap[4 * st.ss[u]];
+                    const T a = ap[4 * (i + u)];
 #pragma unroll
                     for (int j = 0; j < 4; j++) acc[j] = Mma<T>::mma(a, st.w[u][j], acc[j]);
                 }
@@ -375,7 +368,8 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
         const int o = lane & 15, pt4 = lane >> 4;   // output o, a quarter of the hidden units each
         const int oc = min(o, no - 1);
         T mid = 0;
-        for (int i = pt4 * 25; i < pt4 * 25 + 25; i++) mid = mid + w2s[oc + i * no] * ar[i];
+#pragma unroll
+        for (int i = 0; i < 25; i++) mid = mid + w2s[oc + (pt4 * 25 + i) * no] * ar[pt4 * 25 + i];
         mid += __shfl_xor(mid, 16);
         mid += __shfl_xor(mid, 32);
         const T e = rexp(mid + b2s[oc]);
@@ -496,6 +490,7 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
     // cube, 11 tap tiles.  Every wave builds the delta image of its own sample; an image covers kc
     // k-steps of positions at a time (nch chunks) where a whole one would not fit.
     T *out = part + (long)blockIdx.x * (F * K + F);
+    const int q64 = 64 / mre, r64 = 64 - q64 * mre;
     if (ms > TILE_ACC_MS) {
         // Full tiles: every wave multiplies its own sample (all 22 products: 22 MFMAs per 13 operand
         // reads), then the waves' accumulators are added in sample order through LDS, four tap tiles
@@ -512,10 +507,16 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
                 if (nks <= 0) break;
                 for (int e = lane; e < 2 * L.ldd; e += 64) dl[e] = 0;
                 wave_sync();
+                int f = lane / mre, m = lane - f * mre;   // feature p = lane + 64 i as (filter, pooled position), stepped
                 for (int p = lane; p < pout; p += 64) {
-                    const int f = p / mre, m = p - f * mre;
                     const int tt = 2 * m + (int)pxr[p] - t_lo;
                     if (tt >= 0 && tt < 4 * L.kc) dl[(f >> 4) * L.ldd + tt * LDWK + (f & 15)] = plr[p];
+                    f += q64;
+                    m += r64;
+                    if (m >= mre) {
+                        m -= mre;
+                        f++;
+                    }
                 }
                 wave_sync();
                 const T *ap0 = dl + kq * LDWK + col, *ap1 = ap0 + L.ldd;
@@ -585,10 +586,16 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
             if (mine) {
                 for (int e = lane; e < 2 * L.ldd; e += 64) dl[e] = 0;
                 wave_sync();
+                int f = lane / mre, m = lane - f * mre;   // feature p = lane + 64 i as (filter, pooled position), stepped
                 for (int p = lane; p < pout; p += 64) {
-                    const int f = p / mre, m = p - f * mre;
                     const int tt = 2 * m + (int)pxr[p] - t_lo;
                     if (tt >= 0 && tt < 4 * L.kc) dl[(f >> 4) * L.ldd + tt * LDWK + (f & 15)] = plr[p];
+                    f += q64;
+                    m += r64;
+                    if (m >= mre) {
+                        m -= mre;
+                        f++;
+                    }
                 }
             }
             lds_barrier();   // every sample's image is complete
