@@ -321,6 +321,37 @@ def test_mbgd_fused_step_matches_oracle(dtype, z, B, lr, mbgd_path):
             assert np.all(out[d.off_b0:d.off_w1] == 0)
 
 
+@pytest.mark.parametrize("dtype,z,B,lr", [(np.float32, 103, 2045, 0.002),    # full tiles of eight, the last one ragged
+                                          (np.float32, 200, 1797, 0.002),    # full tiles, delta image in four chunks
+                                          (np.float32, 224, 1024, 0.004),    # four samples per tile
+                                          (np.float32, 448, 1000, 0.002),    # four waves per workgroup
+                                          (np.float64, 60, 2048, 0.5),       # fp64, full tiles
+                                          (np.float64, 176, 1024, 0.5)])     # fp64, four waves
+def test_mbgd_large_batches_match_oracle(dtype, z, B, lr, monkeypatch):
+    """Batches large enough for every form of the sample-tile kernel (full tiles, ragged last tile,
+    chunked delta images, four-wave workgroups) and for the one-pass batch reduction, two steps each,
+    on the path the library picks by itself and on the layer kernels."""
+    params, cubes, onehot = make_problem(z, 2 * B, 23 + z, dtype)
+    d = orc.dims(z)
+    c_gpu, o_gpu = dev(cubes), dev(onehot)
+    p_ref = params.copy()
+    refs = []
+    for i0 in range(2):
+        lv_ref, _, _ = orc.mbgd_step(p_ref, cubes, onehot, i0 * B, B, z, dtype(lr), want_grad=False)
+        refs.append((lv_ref, p_ref.copy()))
+    for path in (None, "tile", "layers"):
+        if path:
+            monkeypatch.setenv("CCNN_MBGD_PATH", path)
+        else:
+            monkeypatch.delenv("CCNN_MBGD_PATH", raising=False)
+        p_gpu = dev(params)
+        ws = ops.Workspace()
+        for i0 in range(2):
+            lv = ops.mbgd_step(p_gpu, c_gpu, o_gpu, i0 * B, B, z, lr, workspace=ws)
+            assert relerr(lv.cpu().numpy(), refs[i0][0]) < TOL[dtype], (path, i0)
+            parity.assert_groups(p_gpu.cpu().numpy(), refs[i0][1], d, TOL[dtype], f"parameters, path {path}, step {i0}")
+
+
 def test_adagrad_update_matches_oracle():
     rng = np.random.default_rng(1)
     n = 5000
