@@ -40,3 +40,21 @@ def test_host_only_entry_points_work_without_gpu():
         raise AssertionError("expected CcnnError")
     except L.CcnnError as e:
         assert e.code == -1
+
+
+def test_step_path_choice_needs_no_gpu(monkeypatch):
+    """ccnn_mbgd_path and the workspace size that follows it depend on the batch, the geometry and
+    the element size only (never on a device), and CCNN_MBGD_PATH overrides the choice."""
+    lib = L.load()
+    monkeypatch.delenv("CCNN_MBGD_PATH", raising=False)
+    assert lib.ccnn_mbgd_path(128, 103, 4) == 0            # the reference's batch sizes: one workgroup per sample
+    assert lib.ccnn_mbgd_path(2048, 103, 4) == 1           # large batches: a tile of samples per workgroup
+    assert lib.ccnn_mbgd_path(600, 200, 4) == 0 and lib.ccnn_mbgd_path(704, 200, 4) == 1
+    assert lib.ccnn_mbgd_path(2048, 448, 8) == 2           # no tile fits the LDS: one launch per layer
+    assert lib.ccnn_mbgd_path(0, 103, 4) < 0 and lib.ccnn_mbgd_path(128, 103, 2) < 0
+    fused = lib.ccnn_mbgd_workspace_bytes(2048, 103, 4)
+    monkeypatch.setenv("CCNN_MBGD_PATH", "fused")
+    assert lib.ccnn_mbgd_path(2048, 103, 4) == 0
+    assert lib.ccnn_mbgd_workspace_bytes(2048, 103, 4) > fused    # a conv-gradient row per sample, not per tile
+    monkeypatch.setenv("CCNN_MBGD_PATH", "layers")
+    assert lib.ccnn_mbgd_path(128, 103, 4) == 2
