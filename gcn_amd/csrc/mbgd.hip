@@ -17,6 +17,12 @@
 // A launch boundary costs about as much as one of these kernels' whole run, so the
 // per-sample chain is fused rather than batched layer by layer; FC1 (100 x Pout) is a
 // matrix-vector product per sample here, read through L2.
+//
+// That is the step at the reference's batch sizes.  Batches of several hundred samples and more
+// take tile_fwd_bwd (tile.hip: a tile of samples per workgroup, FC1 as a matrix product that
+// reads W1 once per tile) or, where no tile fits the LDS, the layer kernels below
+// (conv_pool_fwd<TRAIN> + fc_head_fwd<TRAIN> of forward.hip, dpool_bwd, conv_bwd_batch), and
+// grad_reduce_big for the batch sums; step_path() chooses.
 #include <mutex>
 
 #include <cstdlib>
