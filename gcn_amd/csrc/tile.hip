@@ -521,7 +521,6 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
                 wave_sync();
                 const T *ap0 = dl + kq * LDWK + col, *ap1 = ap0 + L.ldd;
                 const T *bp = cube + WSTEP * (t_lo + kq) + col;
-#pragma unroll 2
                 for (int k = 0; k < nks; k++) {
                     const T a0 = ap0[4 * k * LDWK], a1 = ap1[4 * k * LDWK];
                     T b[11];
