@@ -1131,9 +1131,9 @@ inline StepPath step_path(int B, const ccnn_dims_t &d, TilePlan *plan)
         if (!strcmp(e, "batched") || !strcmp(e, "tile")) return fits ? StepPath::TILE : StepPath::LAYERS;
     }
     const int tile_min_b = (sizeof(T) == 8 || d.z <= 128) ? 512 : 704;
-    // one round of workgroups, or several rounds of FULL tiles (z = 224, fp32, B = 2048: tiles of
-    // four samples in two rounds take 197 us where the layer kernels take 129)
-    const bool rounds_ok = tp.tiles <= 256 || (sizeof(T) == 4 && tp.ms == 8);
+    // one round of workgroups, or several rounds of FULL tiles at small band counts (fp32, B = 4096:
+    // 110 us against the layer kernels' 120 at z = 103, but 210 against 198 at z = 224)
+    const bool rounds_ok = tp.tiles <= 256 || (sizeof(T) == 4 && tp.ms == 8 && d.z <= 128);
     if (fits && B >= tile_min_b && rounds_ok) return StepPath::TILE;
     return B >= BATCHED_MIN_B ? StepPath::LAYERS : StepPath::FUSED;
 }

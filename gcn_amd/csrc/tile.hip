@@ -81,7 +81,7 @@ __host__ __device__ inline TileLayout tile_layout(int re, int mre, int nwv, int 
     L.lta = o;  o += 8 * 16;
     L.ltb = o;  o += 8 * 16;
     L.lab = o;  o += 8 * 16;    // ints (an int is no larger than T)
-    L.bs = o;   o += 8 * 32;
+    L.bs = L.lta;               // [8][32] conv-bias sums: written after the head, when the loss terms (lta | ltb) are dead
     L.rb = o;   o += L.b1_len;
     L.cube = o; o += nwv * L.cube_pad;
     L.total = o;

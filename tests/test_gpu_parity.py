@@ -324,6 +324,7 @@ def test_mbgd_fused_step_matches_oracle(dtype, z, B, lr, mbgd_path):
 @pytest.mark.parametrize("dtype,z,B,lr", [(np.float32, 103, 2045, 0.002),    # full tiles of eight, the last one ragged
                                           (np.float32, 200, 1797, 0.002),    # full tiles, delta image in four chunks
                                           (np.float32, 224, 1024, 0.004),    # four samples per tile
+                                          (np.float32, 224, 2043, 0.002),    # the largest shape that fits eight samples
                                           (np.float32, 448, 1000, 0.002),    # four waves per workgroup
                                           (np.float64, 60, 2048, 0.5),       # fp64, full tiles
                                           (np.float64, 176, 1024, 0.5)])     # fp64, four waves
