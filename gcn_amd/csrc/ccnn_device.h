@@ -392,6 +392,42 @@ __device__ __forceinline__ typename Mma<T>::acc_t mma_chain(const T *ap, const T
     return acc;
 }
 
+// NT chains that share their B operand (NT position tiles against one filter tile), run together:
+// a k-step's B fragment is read once and feeds NT matrix instructions, so the LDS serves
+// (NT + 1) / NT operand reads per instruction instead of two, and the NT accumulators give the
+// matrix pipe independent work without splitting a chain in two.  ap[t] walks tile t's A along k.
+template <typename T, int KS, int NT>
+__device__ __forceinline__ void mma_chain_n(const T *const (&ap)[NT], const T *bp, typename Mma<T>::acc_t (&acc)[NT])
+{
+    constexpr int NB4 = (KS + 3) / 4;   // batches of up to four k-steps
+    T a[2][4][NT], b[2][4];
+    auto load = [&](int bi, int set) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (4 * bi + u < KS) {
+                b[set][u] = bp[4 * (4 * bi + u) * LDWK];
+#pragma unroll
+                for (int t = 0; t < NT; t++) a[set][u][t] = ap[t][4 * (4 * bi + u)];
+            }
+        }
+    };
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = typename Mma<T>::acc_t{0, 0, 0, 0};
+    load(0, 0);
+#pragma unroll
+    for (int bi = 0; bi < NB4; bi++) {
+        const int set = bi & 1;
+        if (bi + 1 < NB4) load(bi + 1, set ^ 1);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (4 * bi + u < KS) {
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc[t] = Mma<T>::mma(a[set][u][t], b[set][u], acc[t]);
+            }
+        }
+    }
+}
+
 // Orders this wave's LDS traffic: everything its lanes wrote before is visible to all its
 // lanes after (the LDS serves one wave's requests in order; this keeps the compiler from
 // moving accesses across and waits for outstanding ones).  No other wave is involved.
@@ -457,12 +493,37 @@ __device__ __forceinline__ void conv_pool_chain(const T *cube, const T *wl, int 
     }
 }
 
+// Position tiles t0 .. t0 + NT - 1 of filters 0..15 as one group of chains (mma_chain_n).
+template <typename T, int NT, typename Put>
+__device__ __forceinline__ void conv_pool_group(const T *cube, const T *wl, int re, int t0, T bias0, int lane, Put put)
+{
+    const int col = lane & 15, kq = lane >> 4;
+    const T *ap[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) ap[t] = cube + WSTEP * ((t0 + t) * 16 + col) + kq;
+    typename Mma<T>::acc_t acc[NT];
+    mma_chain_n<T, KSTEPS0, NT>(ap, wl + kq * LDWK + col, acc);
+#pragma unroll
+    for (int t = 0; t < NT; t++) pool_tile(acc[t], bias0, col, true, (t0 + t) * 16, re, lane, put);
+}
+
+// All chains of one sample by one wave: the position tiles of filters 0..15 in groups of three
+// (or two) that share the filter fragments, then the packed-tile chains.
 template <typename T, typename Put>
 __device__ __forceinline__ void conv_pool_wave(const T *cube, const T *wl, int re, T bias0, T biasx, int lane,
                                                Put put)
 {
-    const int nc = conv_chains(re);
-    for (int c = 0; c < nc; c++) conv_pool_chain<T>(cube, wl, re, c, bias0, biasx, lane, put);
+    const int mt = conv_mtiles(re), nc = conv_chains(re);
+    int t = 0;
+    while (mt - t >= 3 && mt - t != 4) {
+        conv_pool_group<T, 3>(cube, wl, re, t, bias0, lane, put);
+        t += 3;
+    }
+    while (mt - t >= 2) {
+        conv_pool_group<T, 2>(cube, wl, re, t, bias0, lane, put);
+        t += 2;
+    }
+    for (int c = t; c < nc; c++) conv_pool_chain<T>(cube, wl, re, c, bias0, biasx, lane, put);
 }
 
 // Stages the 20 x 171 filters as conv_pool_wave wants them (zero taps and columns included), by a

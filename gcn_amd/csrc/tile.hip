@@ -265,7 +265,14 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
     // ---- conv + tanh + pool: the tile's (sample, chain) jobs dealt to the waves ----------------
     // With a full tile a wave gets the chains of its own sample; with fewer samples than waves a
     // sample's chains spread over several waves.
-    {
+    if (nb == nwv) {
+        // a full tile: every wave runs all chains of its own sample, the position tiles in groups
+        // that share their filter fragments
+        conv_pool_wave<T>(cube, rb, re, bias0, biasx, lane, [&](int f, int m, T v, int bt) {
+            plr[f * mre + m] = v;
+            pxr[f * mre + m] = (unsigned char)(bt - 2 * m);   // which member of the pair won
+        });
+    } else {
         const int nc = conv_chains(re);
         for (int job = wave; job < nb * nc; job += nwv) {
             const int c = job / nb, s = job - c * nb;
@@ -273,7 +280,7 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
             unsigned char *pxs = px + s * pout;
             conv_pool_chain<T>(base + L.cube + s * L.cube_pad, rb, re, c, bias0, biasx, lane, [&](int f, int m, T v, int bt) {
                 ps[f * mre + m] = v;
-                pxs[f * mre + m] = (unsigned char)(bt - 2 * m);   // which member of the pair won
+                pxs[f * mre + m] = (unsigned char)(bt - 2 * m);
             });
         }
     }
