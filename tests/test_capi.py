@@ -58,3 +58,31 @@ def test_step_path_choice_needs_no_gpu(monkeypatch):
     assert lib.ccnn_mbgd_workspace_bytes(2048, 103, 4) > fused    # a conv-gradient row per sample, not per tile
     monkeypatch.setenv("CCNN_MBGD_PATH", "layers")
     assert lib.ccnn_mbgd_path(128, 103, 4) == 2
+
+
+def test_tile_plans_fit_the_lds_for_every_geometry():
+    """tile_plan (the host-side choice of waves, samples per tile and delta-image chunks of the
+    sample-tile kernel) never asks for more LDS than a workgroup may have, covers the batch, and
+    keeps one sample per wave - for every band count and both element sizes."""
+    import ctypes as C
+
+    class Plan(C.Structure):
+        _fields_ = [("nwv", C.c_int), ("ms", C.c_int), ("nch", C.c_int), ("smem", C.c_size_t), ("tiles", C.c_int)]
+
+    lib = L.load()
+    fits = 0
+    for es, sym in ((4, "_ZN4ccnn9tile_planIfEEbiRK9ccnn_dimsPNS_8TilePlanE"), (8, "_ZN4ccnn9tile_planIdEEbiRK9ccnn_dimsPNS_8TilePlanE")):
+        fn = getattr(lib, sym)
+        fn.restype = C.c_bool
+        for z in range(21, 449):
+            d = L.dims(z)
+            for B in (1, 7, 256, 600, 2048, 5000):
+                p = Plan()
+                if not fn(B, C.byref(d), C.byref(p)):
+                    assert lib.ccnn_mbgd_path(B, z, es) != 1      # no tile: the library must not pick that path
+                    continue
+                fits += 1
+                assert p.smem <= 160 * 1024, (z, B, es, p.smem)
+                assert p.nwv in (4, 8) and 1 <= p.ms <= p.nwv and p.nch in (1, 2, 4, 8)
+                assert p.tiles == (B + p.ms - 1) // p.ms
+    assert fits > 3000
