@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 from gcn_amd import lib as L, ops, prep  # noqa: E402
 
 z, B = 103, int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-os.environ["CCNN_MBGD_PATH"] = "batched"
+os.environ["CCNN_MBGD_PATH"] = "layers"
 d = L.dims(z)
 rng = np.random.default_rng(1)
 cubes = torch.from_numpy(rng.random((B, 9 * z)).astype(np.float32)).cuda()
