@@ -43,6 +43,7 @@ namespace ccnn {
 constexpr int TILE_LDS_LIMIT = 160 * 1024;
 constexpr int TILE_RED = 2048;    // values per wave in one round of the conv-gradient reduction (4 tap tiles x 2 filter tiles)
 constexpr int TILE_ACC_MS = 4;    // up to this many samples per tile the conv gradient is summed in the accumulators
+constexpr int TILE_DEFAULT_WAVES = 16;
 constexpr int TILE_ZN = 128;      // columns of an FC1 partial-sum row (neurons in the permuted order below: 64 T + 4 col + j)
 
 // LDS carve (elements of T; every region a multiple of 4 elements so 16-byte accesses stay aligned).
@@ -62,12 +63,13 @@ __host__ __device__ inline TileLayout tile_layout(int re, int mre, int nwv, int 
     L.kc = (ks + nch - 1) / nch;              // k-steps (of four positions) per delta-image chunk
     L.ldd = 4 * L.kc * LDWK;                  // one position-major delta tile [4 kc][16 filters]
     L.cube_pad = (conv_cube_pad(re) + 3) & ~3;
+    const int ns = nwv < 8 ? nwv : 8;                             // sample slots (cube, delta image, reduction row): one per sample
     int b1 = WP_LEN;                                              // conv filters (forward)
     if (b1 < (nwv / 2) * 8 * TILE_ZN) b1 = (nwv / 2) * 8 * TILE_ZN;   // FC1 partial sums [K split][8][128]
     if (b1 < ms * pout) b1 = ms * pout;                           // delta x tanh' (the conv-bias path)
-    if (b1 < nwv * 2 * L.ldd) b1 = nwv * 2 * L.ldd;               // per-wave delta images
-    if (ms > TILE_ACC_MS && b1 + nwv * L.cube_pad < nwv * TILE_RED)
-        b1 = nwv * (TILE_RED - L.cube_pad);                       // conv-gradient reduction rounds (they run over into the cubes)
+    if (b1 < ns * 2 * L.ldd) b1 = ns * 2 * L.ldd;                 // per-sample delta images
+    if (ms > TILE_ACC_MS && b1 + ns * L.cube_pad < ns * TILE_RED)
+        b1 = ns * (TILE_RED - L.cube_pad);                        // conv-gradient reduction rounds (they run over into the cubes)
     L.b1_len = (b1 + 3) & ~3;
     int o = 0;
     L.pl = o;   o += ms * L.pld;
@@ -83,11 +85,23 @@ __host__ __device__ inline TileLayout tile_layout(int re, int mre, int nwv, int 
     L.lab = o;  o += 8 * 16;    // ints (an int is no larger than T)
     L.bs = L.lta;               // [8][32] conv-bias sums: written after the head, when the loss terms (lta | ltb) are dead
     L.rb = o;   o += L.b1_len;
-    L.cube = o; o += nwv * L.cube_pad;
+    L.cube = o; o += ns * L.cube_pad;
     L.total = o;
     L.px_off = (size_t)o * sizeof(T);
     L.bytes = L.px_off + (size_t)((ms * pout + 15) & ~15);
     return L;
+}
+
+// Waves per workgroup to try first.  Sixteen (four per SIMD, 128 registers each) for full fp32 tiles:
+// two waves share a sample's conv chains and its conv-gradient products - 45.9 -> 43.1 us at 2048
+// samples of 103 bands, 82 -> 76 us at 200 bands (CCNN_TILE_WAVES=8|16 overrides: tests run both).
+template <typename T>
+inline int tile_max_waves(int ms)
+{
+    if (sizeof(T) != 4 || ms <= TILE_ACC_MS) return 8;
+    const char *e = getenv("CCNN_TILE_WAVES");
+    const int forced = e ? atoi(e) : 0;
+    return forced == 8 || forced == 16 ? forced : TILE_DEFAULT_WAVES;
 }
 
 template <typename T>
@@ -99,7 +113,7 @@ bool tile_plan(int B, const ccnn_dims_t &d, TilePlan *out)
     if (want < 1) want = 1;
     if (want > 8) want = 8;
     for (int ms = want; ms >= 1; ms--) {
-        for (int nwv = 8; nwv >= 4; nwv >>= 1) {
+        for (int nwv = tile_max_waves<T>(ms); nwv >= 4; nwv >>= 1) {
             if (ms > nwv) continue;
             for (int nch = 1; nch <= 8; nch <<= 1) {
                 const TileLayout L = tile_layout<T>(d.re, d.mre, nwv, ms, nch);
@@ -153,6 +167,7 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
     typedef typename Vec16<T>::type V;
     constexpr int VW = Vec16<T>::W;
     constexpr int nt = 64 * NWV, nwv = NWV;
+    constexpr int NS = NWV < 8 ? NWV : 8;   // sample slots
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15, kq = lane >> 4;
     const int re = d.re, mre = d.mre, pout = d.pout, no = NO ? NO : d.n_classes;
@@ -162,7 +177,8 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
     T *b2s = base + L.b2v, *es = base + L.es, *d2s = base + L.d2, *lta = base + L.lta, *ltb = base + L.ltb;
     int *labs = reinterpret_cast<int *>(base + L.lab);
     T *bs = base + L.bs, *rb = base + L.rb;
-    T *cube = base + L.cube + wave * L.cube_pad;
+    const bool slot = wave < NS;            // this wave stages a sample slot's cube
+    T *cube = base + L.cube + (slot ? wave : 0) * L.cube_pad;
     unsigned char *px = reinterpret_cast<unsigned char *>(smem + L.px_off);
 
     const int r0 = blockIdx.x * ms;
@@ -219,11 +235,11 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
             }
         }
         TT(13);
-        for (int e = d.cube + lane; e < L.cube_pad; e += 64) cube[e] = 0;
+        for (int e = d.cube + lane; slot && e < L.cube_pad; e += 64) cube[e] = 0;
 #pragma unroll
         for (int u = 0; u < 16; u++) {
             const int e = u * 64 + lane;
-            if (e < d.cube) cube[e] = t0[u];
+            if (slot && e < d.cube) cube[e] = t0[u];
         }
         for (int e0 = 1024; e0 < d.cube; e0 += 1024) {
             T t[16];
@@ -232,7 +248,7 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
 #pragma unroll
             for (int u = 0; u < 16; u++) {
                 const int e = e0 + u * 64 + lane;
-                if (e < d.cube) cube[e] = t[u];
+                if (slot && e < d.cube) cube[e] = t[u];
             }
         }
     }
@@ -243,7 +259,7 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
     // by the workgroup number, so that at any moment the workgroups of an XCD pull from different
     // L2 channels instead of queueing on the same lines.
     constexpr int KQ = nwv >> 1;
-    constexpr int U = sizeof(T) == 4 ? 16 : 4;   // k-steps of W1 per register set, two sets
+    constexpr int U = sizeof(T) == 4 ? (NWV == 16 ? 8 : 16) : 4;   // k-steps of W1 per register set, two sets
     const int T2 = wave & 1, q = ((wave >> 1) + blockIdx.x) & (KQ - 1);
     const int ks1 = pout >> 2, kper = (ks1 + KQ - 1) / KQ;
     const int s_lo = q * kper, s_hi = min(s_lo + kper, ks1);
@@ -363,7 +379,7 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
         const int t = min(i, ntp - 1) + prot;
         return t >= ntp ? t - ntp : t;
     };
-    constexpr int NPF = sizeof(T) == 4 ? 4 : 2;   // tiles in flight per wave
+    constexpr int NPF = sizeof(T) == 4 && NWV < 16 ? 4 : 2;   // tiles in flight per wave
     V wq[NPF][NG];
 #pragma unroll
     for (int h = 0; h < NPF; h++) w1_tile(tile_of(wave + h * nwv), wq[h]);
@@ -498,7 +514,88 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
     // k-steps of positions at a time (nch chunks) where a whole one would not fit.
     T *out = part + (long)blockIdx.x * (F * K + F);
     const int q64 = 64 / mre, r64 = 64 - q64 * mre;
-    if (ms > TILE_ACC_MS) {
+    if (NWV == 16 && ms > TILE_ACC_MS) {
+        // Full tiles, sixteen waves: waves s and s + 8 share sample s - they build its delta image
+        // together and split its 11 tap tiles (0..5 | 6..10, both filter tiles each); the samples'
+        // accumulators are then added in sample order through LDS, four tap tiles a round.
+        const int sw = wave & 7, hf = wave >> 3;
+        const bool part = sw < nb;
+        const int j0 = hf ? 6 : 0, nj = hf ? 5 : 6;
+        typename Mma<T>::acc_t c0[6], c1[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) c0[j] = c1[j] = typename Mma<T>::acc_t{0, 0, 0, 0};
+        const int ks = (re + 3) >> 2;
+        T *dl = rb + sw * 2 * L.ldd;
+        const T *cube_s = base + L.cube + sw * L.cube_pad;
+        const T *pls = pl + (part ? sw : 0) * L.pld;
+        const unsigned char *pxs = px + (part ? sw : 0) * pout;
+        for (int ch = 0; ch < nch; ch++) {
+            const int t_lo = 4 * L.kc * ch;
+            const int nks = min(L.kc, ks - L.kc * ch);
+            if (nks <= 0) break;
+            if (part)
+                for (int e = lane + 64 * hf; e < 2 * L.ldd; e += 128) dl[e] = 0;
+            lds_barrier();
+            if (part) {
+                for (int p = lane + 64 * hf; p < pout; p += 128) {
+                    const int f = p / mre, m = p - f * mre;
+                    const int tt = 2 * m + (int)pxs[p] - t_lo;
+                    if (tt >= 0 && tt < 4 * L.kc) dl[(f >> 4) * L.ldd + tt * LDWK + (f & 15)] = pls[p];
+                }
+            }
+            lds_barrier();
+            if (part) {
+                const T *ap0 = dl + kq * LDWK + col, *ap1 = ap0 + L.ldd;
+                const T *bp = cube_s + WSTEP * (t_lo + kq) + 16 * j0 + col;
+                for (int k = 0; k < nks; k++) {
+                    const T a0 = ap0[4 * k * LDWK], a1 = ap1[4 * k * LDWK];
+                    T b[6];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) b[j] = bp[4 * k * WSTEP + 16 * (j < nj ? j : 0)];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        if (j < nj) {
+                            c0[j] = Mma<T>::mma(a0, b[j], c0[j]);
+                            c1[j] = Mma<T>::mma(a1, b[j], c1[j]);
+                        }
+                    }
+                }
+            }
+            if (ch + 1 < nch) lds_barrier();   // the image is zeroed again next round
+        }
+        lds_barrier();
+        TT(9);
+#pragma unroll
+        for (int g = 0; g < 3; g++) {
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                const int j = 4 * g + jj;
+                if (j < 11) {
+                    const int owner = j >= 6 ? 1 : 0, lj = j - 6 * owner;   // compile-time after unrolling
+                    if (hf == owner) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            rb[sw * TILE_RED + (jj * 2 + 0) * 256 + r * 64 + lane] = c0[lj][r];
+                            rb[sw * TILE_RED + (jj * 2 + 1) * 256 + r * 64 + lane] = c1[lj][r];
+                        }
+                    }
+                }
+            }
+            lds_barrier();
+            for (int e = tid; e < TILE_RED; e += nt) {
+                const int jj = e >> 9, ft = (e >> 8) & 1, r = (e >> 6) & 3, ln = e & 63;
+                const int j = 4 * g + jj;
+                const int tap = 16 * j + (ln & 15), f = 16 * ft + Mma<T>::row(ln, r);
+                if (j < 11 && tap < K && f < F) {
+                    T s = 0;
+#pragma unroll
+                    for (int w = 0; w < NS; w++) s = s + rb[w * TILE_RED + e];
+                    out[f * K + tap] = s / re;   // gcn_mbgd_fp64.cu:491
+                }
+            }
+            if (g < 2) lds_barrier();
+        }
+    } else if (ms > TILE_ACC_MS) {
         // Full tiles: every wave multiplies its own sample (all 22 products: 22 MFMAs per 13 operand
         // reads), then the waves' accumulators are added in sample order through LDS, four tap tiles
         // a round (the round's buffer runs over the delta images into the cubes: both are dead).
@@ -565,7 +662,7 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
                 if (j < 11 && tap < K && f < F) {
                     T s = 0;
 #pragma unroll
-                    for (int w = 0; w < nwv; w++) s = s + rb[w * TILE_RED + e];
+                    for (int w = 0; w < NS; w++) s = s + rb[w * TILE_RED + e];
                     out[f * K + tap] = s / re;   // gcn_mbgd_fp64.cu:491
                 }
             }
@@ -659,6 +756,9 @@ int tile_train(const T *params, const T *cubes, const int *onehot, long first, i
     const bool c13 = d.n_classes == CCNN_CLASSES;
     auto kern = plan.nwv == 8 ? (c13 ? tile_fwd_bwd<T, FLIP, CCNN_CLASSES, 8> : tile_fwd_bwd<T, FLIP, 0, 8>)
                               : (c13 ? tile_fwd_bwd<T, FLIP, CCNN_CLASSES, 4> : tile_fwd_bwd<T, FLIP, 0, 4>);
+    if constexpr (sizeof(T) == 4) {   // (sixteen waves leave 128 registers each: not enough for the fp64 accumulators)
+        if (plan.nwv == 16) kern = c13 ? tile_fwd_bwd<T, FLIP, CCNN_CLASSES, 16> : tile_fwd_bwd<T, FLIP, 0, 16>;
+    }
     if (int e = allow_smem(kern, plan.smem)) return e;
     launch("tile_fwd_bwd", kern, dim3(plan.tiles), dim3(64 * plan.nwv), plan.smem, st, params, cubes, onehot, first, B,
            plan.ms, plan.nch, d, pool, a1, d1, d2, probs, loss_values, part);

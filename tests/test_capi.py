@@ -83,6 +83,6 @@ def test_tile_plans_fit_the_lds_for_every_geometry():
                     continue
                 fits += 1
                 assert p.smem <= 160 * 1024, (z, B, es, p.smem)
-                assert p.nwv in (4, 8) and 1 <= p.ms <= p.nwv and p.nch in (1, 2, 4, 8)
+                assert p.nwv in (4, 8, 16) and 1 <= p.ms <= min(p.nwv, 8) and p.nch in (1, 2, 4, 8)
                 assert p.tiles == (B + p.ms - 1) // p.ms
     assert fits > 3000

@@ -340,8 +340,12 @@ def test_mbgd_large_batches_match_oracle(dtype, z, B, lr, monkeypatch):
     for i0 in range(2):
         lv_ref, _, _ = orc.mbgd_step(p_ref, cubes, onehot, i0 * B, B, z, dtype(lr), want_grad=False)
         refs.append((lv_ref, p_ref.copy()))
-    for path in (None, "tile", "layers"):
-        if path:
+    for path in (None, "tile", "tile8", "layers"):
+        monkeypatch.delenv("CCNN_TILE_WAVES", raising=False)
+        if path == "tile8":       # full fp32 tiles run sixteen waves per workgroup unless told otherwise
+            monkeypatch.setenv("CCNN_MBGD_PATH", "tile")
+            monkeypatch.setenv("CCNN_TILE_WAVES", "8")
+        elif path:
             monkeypatch.setenv("CCNN_MBGD_PATH", path)
         else:
             monkeypatch.delenv("CCNN_MBGD_PATH", raising=False)
