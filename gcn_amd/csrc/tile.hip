@@ -17,18 +17,23 @@
 // per sample, the layer-by-layer kernels hand every intermediate through memory and pay five
 // launches; here the tile's state stays in LDS from the cube to the conv gradient.
 #include <cstdlib>
+#include <type_traits>
 
 #include "ccnn_device.h"
 #include "profile.h"
 #include "train_fwd.h"
 
 // Diagnostic builds only (-DCCNN_TILE_TIMING): thread 0 of workgroup 5 stamps the 100 MHz wall clock
-// at TT(k); ccnn_debug_tile_ticks() returns the stamps of the last launch.
+// at TT(k) (and the shader clock for k < 12, at [20 + k]: their ratio is the clock the phase ran
+// at); ccnn_debug_tile_ticks() returns the stamps of the last launch.
 #ifdef CCNN_TILE_TIMING
 __device__ unsigned long long g_tile_ticks[32];
 #define TT(k)                                                                        \
     do {                                                                             \
-        if (blockIdx.x == 5 && threadIdx.x == 0) g_tile_ticks[k] = wall_clock64();   \
+        if (blockIdx.x == 5 && threadIdx.x == 0) {                                   \
+            g_tile_ticks[k] = wall_clock64();                                        \
+            if ((k) < 12) g_tile_ticks[20 + (k)] = __builtin_amdgcn_s_memtime();     \
+        }                                                                            \
     } while (0)
 extern "C" int ccnn_debug_tile_ticks(unsigned long long *out)
 {
@@ -514,152 +519,149 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
     // k-steps of positions at a time (nch chunks) where a whole one would not fit.
     T *out = part + (long)blockIdx.x * (F * K + F);
     const int q64 = 64 / mre, r64 = 64 - q64 * mre;
-    if (NWV == 16 && ms > TILE_ACC_MS) {
-        // Full tiles, sixteen waves: waves s and s + 8 share sample s - they build its delta image
-        // together and split its 11 tap tiles (0..5 | 6..10, both filter tiles each); the samples'
-        // accumulators are then added in sample order through LDS, four tap tiles a round.
-        const int sw = wave & 7, hf = wave >> 3;
+    if (ms > TILE_ACC_MS) {
+        // Full tiles.  Filters 0..15 as 16 x 16 x 4 products against the 11 tap tiles; filters 16..19
+        // (fp32) on the 16-block 4 x 4 x 1 instruction instead of a second 16-wide tile with twelve
+        // empty rows: rows = the four filters, block b of tap group g = taps 64 g + 4 b .. + 3, one
+        // position per instruction - lane l supplies delta[16 + l % 4][t] and cube[18 t + 64 g + l] and
+        // receives dW0[16 + i][64 g + l] in register i.  Per four positions that is 11 x 32 + 12 x 8
+        // matrix-pipe cycles instead of 22 x 32 (the conv phases run at the pipe's rate, so fewer
+        // instructions is what shortens them).
+        // Eight (or four) waves: every wave multiplies its own sample.  Sixteen waves: waves s and
+        // s + 8 share sample s - they build its delta image together and split the work (tap tiles
+        // 0..4 and tap groups 0, 1 | tap tiles 5..10 and tap group 2).  The samples' accumulators are
+        // then added in sample order through LDS, four tap tiles and one tap group a round (the
+        // round's buffer runs over the delta images into the cubes: both are dead).
+        constexpr bool X4 = sizeof(T) == 4;         // filters 16..19 on the 4 x 4 x 1 instruction
+        constexpr bool PAIR = NWV == 16;
+        constexpr int NC0 = PAIR ? 6 : 11;          // tap tiles per wave
+        constexpr int NXG = PAIR ? 2 : 3;           // tap groups per wave
+        const int sw = PAIR ? (wave & 7) : wave, hf = PAIR ? (wave >> 3) : 0;
         const bool part = sw < nb;
-        const int j0 = hf ? 6 : 0, nj = hf ? 5 : 6;
-        typename Mma<T>::acc_t c0[6], c1[6];
+        const int j0 = hf ? 5 : 0, g0 = hf ? 2 : 0;   // first tap tile and tap group of this wave
+        typename Mma<T>::acc_t c0[NC0], c1[X4 ? 1 : NC0], xd[X4 ? NXG : 1];
 #pragma unroll
-        for (int j = 0; j < 6; j++) c0[j] = c1[j] = typename Mma<T>::acc_t{0, 0, 0, 0};
+        for (int j = 0; j < NC0; j++) c0[j] = typename Mma<T>::acc_t{0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < (X4 ? 1 : NC0); j++) c1[j] = typename Mma<T>::acc_t{0, 0, 0, 0};
+#pragma unroll
+        for (int g = 0; g < (X4 ? NXG : 1); g++) xd[g] = typename Mma<T>::acc_t{0, 0, 0, 0};
         const int ks = (re + 3) >> 2;
-        T *dl = rb + sw * 2 * L.ldd;
-        const T *cube_s = base + L.cube + sw * L.cube_pad;
+        T *dl = rb + (part ? sw : 0) * 2 * L.ldd;
+        const T *cube_s = base + L.cube + (part ? sw : 0) * L.cube_pad;
         const T *pls = pl + (part ? sw : 0) * L.pld;
         const unsigned char *pxs = px + (part ? sw : 0) * pout;
+        constexpr int NBW = PAIR ? 2 : 1;           // waves that build one delta image
         for (int ch = 0; ch < nch; ch++) {
             const int t_lo = 4 * L.kc * ch;
             const int nks = min(L.kc, ks - L.kc * ch);
             if (nks <= 0) break;
             if (part)
-                for (int e = lane + 64 * hf; e < 2 * L.ldd; e += 128) dl[e] = 0;
-            lds_barrier();
+                for (int e = lane + 64 * hf; e < 2 * L.ldd; e += 64 * NBW) dl[e] = 0;
+            if (PAIR) lds_barrier();
+            else wave_sync();
             if (part) {
-                for (int p = lane + 64 * hf; p < pout; p += 128) {
+                for (int p = lane + 64 * hf; p < pout; p += 64 * NBW) {
                     const int f = p / mre, m = p - f * mre;
                     const int tt = 2 * m + (int)pxs[p] - t_lo;
                     if (tt >= 0 && tt < 4 * L.kc) dl[(f >> 4) * L.ldd + tt * LDWK + (f & 15)] = pls[p];
                 }
             }
-            lds_barrier();
+            if (PAIR) lds_barrier();
+            else wave_sync();
             if (part) {
                 const T *ap0 = dl + kq * LDWK + col, *ap1 = ap0 + L.ldd;
                 const T *bp = cube_s + WSTEP * (t_lo + kq) + 16 * j0 + col;
-                for (int k = 0; k < nks; k++) {
-                    const T a0 = ap0[4 * k * LDWK], a1 = ap1[4 * k * LDWK];
-                    T b[6];
+                const T *xa = dl + L.ldd + (lane & 3);                  // delta[16 + lane % 4][.] of the image's second tile
+                const T *xb = cube_s + WSTEP * t_lo + 64 * g0 + lane;   // cube[18 t + 64 g + lane]
+                // NJ tap tiles and NG tap groups, compile-time: a count known only at run time would
+                // put a branch around every matrix instruction
+                auto products = [&](auto nj_c, auto ng_c) {
+                    constexpr int NJ = decltype(nj_c)::value, NG = decltype(ng_c)::value;
+                    for (int k = 0; k < nks; k++) {
+                        const T a0 = ap0[4 * k * LDWK];
+                        T a1 = 0;
+                        if (!X4) a1 = ap1[4 * k * LDWK];
+                        T b[NJ];
 #pragma unroll
-                    for (int j = 0; j < 6; j++) b[j] = bp[4 * k * WSTEP + 16 * (j < nj ? j : 0)];
+                        for (int j = 0; j < NJ; j++) b[j] = bp[4 * k * WSTEP + 16 * j];
+                        T xav[4], xbv[4][NG];
+                        if (X4) {
 #pragma unroll
-                    for (int j = 0; j < 6; j++) {
-                        if (j < nj) {
+                            for (int q = 0; q < 4; q++) {
+                                const int tq = min(t_lo + 4 * k + q, re - 1) - t_lo;   // clamped: positions past the end are skipped below
+                                xav[q] = xa[tq * LDWK];
+#pragma unroll
+                                for (int g = 0; g < NG; g++) xbv[q][g] = xb[tq * WSTEP + 64 * g];
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < NJ; j++) {
                             c0[j] = Mma<T>::mma(a0, b[j], c0[j]);
-                            c1[j] = Mma<T>::mma(a1, b[j], c1[j]);
+                            if (!X4) c1[j] = Mma<T>::mma(a1, b[j], c1[j]);
+                        }
+                        if constexpr (X4) {
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                if (t_lo + 4 * k + q < re) {
+#pragma unroll
+                                    for (int g = 0; g < NG; g++)
+                                        xd[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(xav[q], xbv[q][g], xd[g], 0, 0, 0);
+                                }
+                            }
                         }
                     }
+                };
+                if constexpr (!PAIR) {
+                    products(std::integral_constant<int, 11>{}, std::integral_constant<int, 3>{});
+                } else {
+                    if (hf) products(std::integral_constant<int, 6>{}, std::integral_constant<int, 1>{});
+                    else products(std::integral_constant<int, 5>{}, std::integral_constant<int, 2>{});
                 }
             }
-            if (ch + 1 < nch) lds_barrier();   // the image is zeroed again next round
+            if (ch + 1 < nch) {   // the image is zeroed again next round
+                if (PAIR) lds_barrier();
+                else wave_sync();
+            }
         }
         lds_barrier();
         TT(9);
+        // rounds: tap tiles 4 g .. 4 g + 3 of filters 0..15 (and of 16..31 without X4), tap group g of filters 16..19
 #pragma unroll
         for (int g = 0; g < 3; g++) {
 #pragma unroll
             for (int jj = 0; jj < 4; jj++) {
                 const int j = 4 * g + jj;
                 if (j < 11) {
-                    const int owner = j >= 6 ? 1 : 0, lj = j - 6 * owner;   // compile-time after unrolling
+                    const int owner = PAIR && j >= 5 ? 1 : 0, lj = j - 5 * owner;   // compile-time after unrolling
                     if (hf == owner) {
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
                             rb[sw * TILE_RED + (jj * 2 + 0) * 256 + r * 64 + lane] = c0[lj][r];
-                            rb[sw * TILE_RED + (jj * 2 + 1) * 256 + r * 64 + lane] = c1[lj][r];
+                            if (!X4) rb[sw * TILE_RED + (jj * 2 + 1) * 256 + r * 64 + lane] = c1[X4 ? 0 : lj][r];
                         }
                     }
                 }
             }
-            lds_barrier();
-            for (int e = tid; e < TILE_RED; e += nt) {
-                const int jj = e >> 9, ft = (e >> 8) & 1, r = (e >> 6) & 3, ln = e & 63;
-                const int j = 4 * g + jj;
-                const int tap = 16 * j + (ln & 15), f = 16 * ft + Mma<T>::row(ln, r);
-                if (j < 11 && tap < K && f < F) {
-                    T s = 0;
+            if (X4) {
+                const int owner = PAIR && g == 2 ? 1 : 0, lg = PAIR ? (g == 2 ? 0 : g) : g;
+                if (hf == owner) {
 #pragma unroll
-                    for (int w = 0; w < NS; w++) s = s + rb[w * TILE_RED + e];
-                    out[f * K + tap] = s / re;   // gcn_mbgd_fp64.cu:491
-                }
-            }
-            if (g < 2) lds_barrier();
-        }
-    } else if (ms > TILE_ACC_MS) {
-        // Full tiles: every wave multiplies its own sample (all 22 products: 22 MFMAs per 13 operand
-        // reads), then the waves' accumulators are added in sample order through LDS, four tap tiles
-        // a round (the round's buffer runs over the delta images into the cubes: both are dead).
-        typename Mma<T>::acc_t c0[11], c1[11];
-#pragma unroll
-        for (int j = 0; j < 11; j++) c0[j] = c1[j] = typename Mma<T>::acc_t{0, 0, 0, 0};
-        if (mine) {
-            const int ks = (re + 3) >> 2;
-            T *dl = rb + wave * 2 * L.ldd;
-            for (int ch = 0; ch < nch; ch++) {
-                const int t_lo = 4 * L.kc * ch;
-                const int nks = min(L.kc, ks - L.kc * ch);
-                if (nks <= 0) break;
-                for (int e = lane; e < 2 * L.ldd; e += 64) dl[e] = 0;
-                wave_sync();
-                int f = lane / mre, m = lane - f * mre;   // feature p = lane + 64 i as (filter, pooled position), stepped
-                for (int p = lane; p < pout; p += 64) {
-                    const int tt = 2 * m + (int)pxr[p] - t_lo;
-                    if (tt >= 0 && tt < 4 * L.kc) dl[(f >> 4) * L.ldd + tt * LDWK + (f & 15)] = plr[p];
-                    f += q64;
-                    m += r64;
-                    if (m >= mre) {
-                        m -= mre;
-                        f++;
-                    }
-                }
-                wave_sync();
-                const T *ap0 = dl + kq * LDWK + col, *ap1 = ap0 + L.ldd;
-                const T *bp = cube + WSTEP * (t_lo + kq) + col;
-                for (int k = 0; k < nks; k++) {
-                    const T a0 = ap0[4 * k * LDWK], a1 = ap1[4 * k * LDWK];
-                    T b[11];
-#pragma unroll
-                    for (int j = 0; j < 11; j++) b[j] = bp[4 * k * WSTEP + 16 * j];
-#pragma unroll
-                    for (int j = 0; j < 11; j++) {
-                        c0[j] = Mma<T>::mma(a0, b[j], c0[j]);
-                        c1[j] = Mma<T>::mma(a1, b[j], c1[j]);
-                    }
-                }
-                wave_sync();   // the image is zeroed again next round
-            }
-        }
-        lds_barrier();
-        TT(9);
-#pragma unroll
-        for (int g = 0; g < 3; g++) {
-#pragma unroll
-            for (int jj = 0; jj < 4; jj++) {
-                const int j = 4 * g + jj;
-                if (j < 11) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        rb[wave * TILE_RED + (jj * 2 + 0) * 256 + r * 64 + lane] = c0[j][r];
-                        rb[wave * TILE_RED + (jj * 2 + 1) * 256 + r * 64 + lane] = c1[j][r];
-                    }
+                    for (int i = 0; i < 4; i++) rb[sw * TILE_RED + 256 + i * 64 + lane] = xd[X4 ? lg : 0][i];   // the slot of tile jj = 0, filter tile 1
                 }
             }
             lds_barrier();
             for (int e = tid; e < TILE_RED; e += nt) {
                 const int jj = e >> 9, ft = (e >> 8) & 1, r = (e >> 6) & 3, ln = e & 63;
                 const int j = 4 * g + jj;
-                const int tap = 16 * j + (ln & 15), f = 16 * ft + Mma<T>::row(ln, r);
-                if (j < 11 && tap < K && f < F) {
+                int tap = 16 * j + (ln & 15), f = 16 * ft + Mma<T>::row(ln, r);
+                bool live = j < 11 && tap < K && f < F;
+                if (X4 && ft == 1) {   // only slot (jj = 0, filter tile 1) is in use: filter 16 + r, tap 64 g + ln
+                    tap = 64 * g + ln;
+                    f = 16 + r;
+                    live = jj == 0 && tap < K;
+                }
+                if (live) {
                     T s = 0;
 #pragma unroll
                     for (int w = 0; w < NS; w++) s = s + rb[w * TILE_RED + e];

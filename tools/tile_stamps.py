@@ -33,3 +33,5 @@ print(f"z={z} B={B} {DT.__name__}: " + "  ".join(f"{names[k]}={(t[k + 1] - t[k])
       f"total={(t[10] - t[0]) * 10}ns")
 print("  stage: small operands stored +%dns, barrier (first loads landed) +%dns, filters scattered +%dns"
       % tuple((t[k] - t[0]) * 10 for k in (11, 12, 13)))
+print("  shader clock per phase (GHz): " + "  ".join(
+    f"{names[k]}={(t[21 + k] - t[20 + k]) / ((t[k + 1] - t[k]) * 10.0):.2f}" for k in range(10) if t[k + 1] > t[k]))
