@@ -21,13 +21,15 @@ d = L.dims(z)
 rng = np.random.default_rng(1)
 n = 8192
 cubes = torch.from_numpy(rng.random((n, 9 * z)).astype(dtype)).cuda()
+if os.environ.get("BENCH_ZERO_CUBES"):   # diagnostic: how much of the step time depends on the operand values (power, not work)
+    cubes.zero_()
 oh = np.zeros((n, 13), dtype=np.int32)
 oh[np.arange(n), rng.integers(0, 13, n)] = 1
 oh = torch.from_numpy(oh).cuda()
 p0 = torch.from_numpy(prep.init_params(z, dtype, d.pout)).cuda()
 for path in (os.environ.get("BENCH_PATHS", "fused,tile,layers").split(",")):
     os.environ["CCNN_MBGD_PATH"] = path
-    for B in (64, 128, 256, 512, 1024, 2048, 4096):
+    for B in [int(b) for b in os.environ.get("BENCH_BATCHES", "64,128,256,512,1024,2048,4096").split(",")]:
         if path == "fused" and B > 1024:
             continue
         p = p0.clone()
