@@ -1,7 +1,7 @@
 #!/bin/bash
 # Incremental build of gcn_amd/lib/libccnn_hip.so for development: one object per source
 # (rebuilt only when the source or a header changed), sources compiled in parallel, then linked.
-# __graft_entry__.build() stays the reference build (one hipcc call over all sources).
+# __graft_entry__.build() is the build of record (same flags, its objects under build/obj).
 set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 CSRC="$ROOT/gcn_amd/csrc"
