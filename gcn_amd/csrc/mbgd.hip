@@ -62,7 +62,7 @@ __host__ __device__ inline int up4(int v) { return (v + 3) & ~3; }
 // LDS carve of sample_fwd_bwd, in elements of T (every region a multiple of 4
 // elements so 16-byte accesses stay aligned), then the int region.
 struct FusedLayout {
-    int cube, wl, a0, pl, dp, a1, d1, es, ps, d2, lta, ltb, total;   // element offsets / count
+    int cube, wl, a0, pl, dp, a1, d1, es, ps, d2, total;   // element offsets / count
     int ldd, ks;
     size_t px_off, lab_off, bytes;
 };
@@ -87,8 +87,6 @@ __host__ __device__ inline FusedLayout fused_layout(int re, int mre)
     L.es = o;   o += 16;
     L.ps = o;   o += 16;
     L.d2 = o;   o += 16;
-    L.lta = o;  o += 16;
-    L.ltb = o;  o += 16;
     L.total = o;
     L.px_off = (size_t)o * sizeof(T);
     L.lab_off = L.px_off + (size_t)up4(pout) * sizeof(int);   // 16 ints: the sample's one-hot labels
@@ -196,7 +194,6 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
     T *base = reinterpret_cast<T *>(smem);
     T *cube = base + L.cube, *wl = base + L.wl, *a0 = base + L.a0, *pl = base + L.pl, *dp = base + L.dp;
     T *a1s = base + L.a1, *d1s = base + L.d1, *es = base + L.es, *ps = base + L.ps, *d2s = base + L.d2;
-    T *lta = base + L.lta, *ltb = base + L.ltb;
     int *px = reinterpret_cast<int *>(smem + L.px_off);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15;
@@ -386,19 +383,24 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
         d1s[tid] = dv;
         if (lead) d1_g[row * H + tid] = dv;
     }
-    // the loss terms (a log and an exp each) are nobody's input: an idle wave computes them here
-    if (tid >= NT - 64 && tid < NT - 64 + no) {
+    // the loss (a log and an exp per class, then the ordered sum) is nobody's input: an idle wave
+    // computes it here, lane o the terms of class o
+    if (tid >= NT - 64) {
         const int o = tid - (NT - 64);
-        loss_terms(ps[o], lab[o], &lta[o], &ltb[o]);
+        T ta = 0, tb = 0;
+        int lb = 0;
+        if (o < no) {
+            lb = lab[o];
+            loss_terms(ps[o], lb, &ta, &tb);
+        }
+        const double loss = loss_sum_lanes(ta, tb, lb, no);
+        if (o == 0 && lead) loss_values[row] = loss;
     }
     __syncthreads();
     FB_TICK(7);
 #if CCNN_STOP_PHASE == 4
     return;
 #endif
-    // nothing waits for the loss: one thread adds its terms up while the walk below runs
-    if (tid == NT - 1 && lead) loss_values[row] = loss_sum(lta, ltb, lab, no);
-
     // ---- delta at the pooled features + bp_maxpooling scatter -----------------------
     // dpool[p] = (sum_n W1[n + 100 p] d1[n]) (1 + pool)(1 - pool), gcn_mbgd_fp64.cu:416-434, 450-452
     {

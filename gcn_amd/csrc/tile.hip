@@ -54,7 +54,7 @@ constexpr int TILE_ZN = 128;      // columns of an FC1 partial-sum row (neurons 
 // LDS carve (elements of T; every region a multiple of 4 elements so 16-byte accesses stay aligned).
 struct TileLayout {
     int pld, hld, kc, ldd, cube_pad, b1_len;
-    int pl, a1, d1, w2, b1v, b2v, es, d2, lta, ltb, lab, bs, rb, cube, total;
+    int pl, a1, d1, w2, b1v, b2v, es, d2, bs, rb, cube, total;
     size_t px_off, bytes;
 };
 
@@ -85,10 +85,7 @@ __host__ __device__ inline TileLayout tile_layout(int re, int mre, int nwv, int 
     L.b2v = o;  o += 16;
     L.es = o;   o += 8 * 16;
     L.d2 = o;   o += 8 * 16;
-    L.lta = o;  o += 8 * 16;
-    L.ltb = o;  o += 8 * 16;
-    L.lab = o;  o += 8 * 16;    // ints (an int is no larger than T)
-    L.bs = L.lta;               // [8][32] conv-bias sums: written after the head, when the loss terms (lta | ltb) are dead
+    L.bs = o;   o += 8 * 32;    // [8][32] conv-bias sums
     L.rb = o;   o += L.b1_len;
     L.cube = o; o += ns * L.cube_pad;
     L.total = o;
@@ -179,8 +176,7 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
     const TileLayout L = tile_layout<T>(re, mre, nwv, ms, nch);
     T *base = reinterpret_cast<T *>(smem);
     T *pl = base + L.pl, *a1s = base + L.a1, *d1s = base + L.d1, *w2s = base + L.w2, *b1s = base + L.b1v;
-    T *b2s = base + L.b2v, *es = base + L.es, *d2s = base + L.d2, *lta = base + L.lta, *ltb = base + L.ltb;
-    int *labs = reinterpret_cast<int *>(base + L.lab);
+    T *b2s = base + L.b2v, *es = base + L.es, *d2s = base + L.d2;
     T *bs = base + L.bs, *rb = base + L.rb;
     const bool slot = wave < NS;            // this wave stages a sample slot's cube
     T *cube = base + L.cube + (slot ? wave : 0) * L.cube_pad;
@@ -404,16 +400,17 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
         if (lane < no) es[wave * 16 + lane] = e;
         wave_sync();
         const T p = e / tree_n(es + wave * 16, no);
+        T lt_a = 0, lt_b = 0;   // this lane's class: the loss terms
         if (lane < no) {
             if (probs_g) probs_g[row * no + lane] = p;
             const T dv = (p - lab_g) / no;   // gcn_mbgd_fp64.cu:352
             d2s[wave * 16 + lane] = dv;
             d2_g[row * no + lane] = dv;
-            loss_terms(p, lab_g, &lta[wave * 16 + lane], &ltb[wave * 16 + lane]);
-            labs[wave * 16 + lane] = lab_g;
+            loss_terms(p, lab_g, &lt_a, &lt_b);
         }
         wave_sync();
-        if (lane == 63) loss_values[row] = loss_sum(lta + wave * 16, ltb + wave * 16, labs + wave * 16, no);
+        const double loss = loss_sum_lanes(lt_a, lt_b, lab_g, no);
+        if (lane == 0) loss_values[row] = loss;
         T dd[OMAX];   // entries past the class count are never read by the tree
 #pragma unroll
         for (int oo = 0; oo < OMAX; oo++) dd[oo] = d2s[wave * 16 + oo];
