@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64 * CONV_MAXWAVES) void conv_pool_fwd(const T *__r
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int sidx_all[CONV_MAXWAVES][2][16];   // SCENE: lists of the sample being loaded / the one after
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef CCNN_CONV_CLOCK
     if (tid == 0 && blockIdx.x < 2048) g_conv_wg[3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void fc_head_fwd(const T *__restrict__ params,
     T *base = reinterpret_cast<T *>(smem);
     T *wl = base + L::wl, *pt = base + L::pt, *w2s = base + L::w2, *b1s = base + L::b1, *b2s = base + L::b2;
     T *es = base + L::es, *ps = base + L::ps;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 15, kq = lane >> 4;
     // Tiles of 32 samples: workgroup b starts with tile b; the tiles beyond the grid are handed
     // out through eight counters (workgroup b uses counter b % 8, one eighth of the remaining

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void gather_tile(const T *__restrict__ scene,
     __shared__ int sidx[2][NB * GS];         // [j][s] pixel index, double-buffered by group
     __shared__ long sid[2][GS];              // output row of sample s
     __shared__ T tile[GS][GBANDS * NB + 1];  // odd row stride: lanes walking s hit distinct banks
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long cube_len = (long)NB * z;
     const long ngroups = (n + GS - 1) / GS;
     const int npass = (z + GBANDS - 1) / GBANDS;
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void gather_dense(const T *__restrict__ scene,
     constexpr int DB = DenseCfg<T>::DB;
     __shared__ T reg[DB * DREG];
     __shared__ int shead[DTX * DTY], snext[DTX * DTY];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntx = (x + DTX - 1) / DTX;
     const int t = w.tiles[blockIdx.x];
     const int tx0 = (t % ntx) * DTX, ty0 = (t / ntx) * DTY;

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
     T *cube = base + L.cube, *wl = base + L.wl, *a0 = base + L.a0, *pl = base + L.pl, *dp = base + L.dp;
     T *a1s = base + L.a1, *d1s = base + L.d1, *es = base + L.es, *ps = base + L.ps, *d2s = base + L.d2;
     int *px = reinterpret_cast<int *>(smem + L.px_off);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 15;
     const int re = d.re, mre = d.mre, pout = d.pout, no = NO ? NO : d.n_classes;
     const int half = SPLIT == 2 ? (blockIdx.x >> 3) & 1 : 0;
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int o
     int ok[4] = {-1, -1, -1, -1};   // parameter index of this thread's outputs (-1: none)
     T og[4] = {0, 0, 0, 0};         // and their batch sums
     if (blk < nb_w1) {
-        const int lane = tid & 63, wave = tid >> 6;
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         if (wave < 7) {
             const int col = lane & 15, kq = lane >> 4;
             const int p0 = blk * 16, n0 = wave * 16;
@@ -760,7 +760,7 @@ __global__ __launch_bounds__(DP_THREADS) void dpool_bwd(const T *__restrict__ W1
     typedef typename Vec16<T>::type V;
     constexpr int VW = Vec16<T>::W;
     constexpr int NG = (H + 4 * VW - 1) / (4 * VW);   // vectors per lane along n
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = lane & 15, kq = lane >> 4;
     const int p0 = blockIdx.x * 16;
     const int prow = min(p0 + col, pout - 1);          // clamped: loads stay in bounds, stores masked
@@ -849,7 +849,7 @@ __global__ __launch_bounds__(CB_THREADS) void conv_bwd_batch(const T *__restrict
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ConvBwdLds<T> L(re, mre);
     T *base = reinterpret_cast<T *>(smem);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 15, kq = lane >> 4;
     const int pout = F * mre, ks = (re + 3) >> 2, ldd = 4 * ks * LDWK;
     const int G = gridDim.x;
@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__(GB_THREADS) void grad_reduce_big(int B, int pout, i
                                                               int nb_b1, T *__restrict__ grad, UpdateRule<T> upd)
 {
     __shared__ T red[8 * 256];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int no = NO ? NO : (off_b2 - off_w2) / H;
     int blk = blockIdx.x;
     if (blk < 7 * nb_w1) {

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(SGD_THREADS) void sgd_epoch(double *__restrict__ pa
     double *a1s = base + L.a1, *d1s = base + L.d1, *ps = base + L.ps, *d2s = base + L.d2, *lt = base + L.es;
     double *b0s = base + L.b0;
     int *px = reinterpret_cast<int *>(smem + L.px_off);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int re = d.re, mre = d.mre, cube_len = d.cube, no = NO ? NO : d.n_classes;
     double *W1g = params + d.off_w1 + (long)f * mre * H;
 

@@ -170,7 +170,9 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
     constexpr int VW = Vec16<T>::W;
     constexpr int nt = 64 * NWV, nwv = NWV;
     constexpr int NS = NWV < 8 ? NWV : 8;   // sample slots
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (the wave number through v_readfirstlane: the compiler then keeps everything indexed by it -
+    // job numbers, sample slots, LDS bases - in scalar registers and scalar instructions)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 15, kq = lane >> 4;
     const int re = d.re, mre = d.mre, pout = d.pout, no = NO ? NO : d.n_classes;
     const TileLayout L = tile_layout<T>(re, mre, nwv, ms, nch);

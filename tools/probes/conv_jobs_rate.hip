@@ -5,6 +5,7 @@
 //   V = 0  as in the kernel (results stored to LDS: a float and a byte per pooled value)
 //   V = 1  results summed into a register instead of stored
 //   V = 3  no epilogue at all: the chains alone (mma_chain), accumulators summed into a register
+//   V = 5  as V = 0 with the geometry (positions, pooled positions, samples, strides) in kernel arguments, as the library has it
 //   V = 4  every wave runs all chains of its own sample (conv_pool_wave: position tiles in groups of three)
 //   hipcc --offload-arch=gfx950 -O3 -I../../gcn_amd/csrc -I../../include conv_jobs_rate.hip -o conv_jobs_rate
 #include <hip/hip_runtime.h>
@@ -17,7 +18,7 @@ using namespace ccnn;
 constexpr int RE = 43, MRE = 21, POUT = 420, PLD = 452, NSAMP = 8;
 
 template <int V>
-__global__ __launch_bounds__(1024) void k(const float *src, float *out, unsigned long long *cyc, int reps)
+__global__ __launch_bounds__(1024) void k(const float *src, float *out, unsigned long long *cyc, int reps, int re_a, int mre_a, int nb_a, int pld_a, int pout_a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int cube_pad = conv_cube_pad(RE);
@@ -27,7 +28,8 @@ __global__ __launch_bounds__(1024) void k(const float *src, float *out, unsigned
     for (int i = threadIdx.x; i < total; i += blockDim.x) lds[i] = src[i & 8191];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
-    const int nc = conv_chains(RE), nb = NSAMP;
+    const int re = V == 5 ? re_a : RE, mre = V == 5 ? mre_a : MRE, pld = V == 5 ? pld_a : PLD, pout = V == 5 ? pout_a : POUT;
+    const int nc = conv_chains(re), nb = V == 5 ? nb_a : NSAMP;
     float keep = 0;
     const float bias0 = src[lane & 15], biasx = src[16 + (lane & 3)];
     __syncthreads();
@@ -56,14 +58,14 @@ __global__ __launch_bounds__(1024) void k(const float *src, float *out, unsigned
                 keep += acc[0] + acc[1] + acc[2] + acc[3];
                 continue;
             }
-            float *ps = pl + s * PLD;
-            unsigned char *pxs = px + s * POUT;
-            conv_pool_chain<float>(cubes + s * cube_pad, wl, RE, c, bias0, biasx, lane, [&](int f, int m, float v, int bt) {
+            float *ps = pl + s * pld;
+            unsigned char *pxs = px + s * pout;
+            conv_pool_chain<float>(cubes + s * (V == 5 ? conv_cube_pad(re) : cube_pad), wl, re, c, bias0, biasx, lane, [&](int f, int m, float v, int bt) {
                 if (V == 1) {
                     keep += v + (float)bt;
                 } else {
-                    ps[f * MRE + m] = v;
-                    pxs[f * MRE + m] = (unsigned char)(bt - 2 * m);
+                    ps[f * mre + m] = v;
+                    pxs[f * mre + m] = (unsigned char)(bt - 2 * m);
                 }
             });
         }
@@ -80,7 +82,7 @@ void run(const char *what, int threads, int reps, const float *src, float *out, 
     const int blocks = 256;
     const size_t smem = (size_t)(WP_LEN + NSAMP * conv_cube_pad(RE) + NSAMP * PLD + NSAMP * POUT / 4) * 4;
     hipFuncSetAttribute((const void *)k<V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    for (int r = 0; r < 3; r++) hipLaunchKernelGGL(k<V>, dim3(blocks), dim3(threads), smem, 0, src, out, cyc, reps);
+    for (int r = 0; r < 3; r++) hipLaunchKernelGGL(k<V>, dim3(blocks), dim3(threads), smem, 0, src, out, cyc, reps, RE, MRE, NSAMP, PLD, POUT);
     if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return; }
     std::vector<unsigned long long> h(blocks);
     hipMemcpy(h.data(), cyc, blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost);
@@ -103,6 +105,7 @@ int main()
         run<1>("results kept in a register", threads, 1, src, out, cyc);
         run<0>("as in the kernel, steady state", threads, 8, src, out, cyc);
         run<1>("results kept in a register, steady state", threads, 8, src, out, cyc);
+        run<5>("geometry in kernel arguments", threads, 1, src, out, cyc);
         run<3>("chains only", threads, 1, src, out, cyc);
         run<3>("chains only, steady state", threads, 8, src, out, cyc);
         if (threads == 512) {
