@@ -262,20 +262,29 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
     // by the workgroup number, so that at any moment the workgroups of an XCD pull from different
     // L2 channels instead of queueing on the same lines.
     constexpr int KQ = nwv >> 1;
-    constexpr int U = sizeof(T) == 4 ? (NWV == 16 ? 8 : 16) : 4;   // k-steps of W1 per register set, two sets
+    // fp32: FC1 runs on the 16-block 4 x 4 x 1 instruction (below), one pooled feature per instruction,
+    // and a register of a set holds one W1 value; fp64: 16 x 16 x 4 tiles, a set register = one k-step
+    constexpr bool FC4 = sizeof(T) == 4;
+    constexpr int U = FC4 ? (NWV == 16 ? 16 : 32) : 4;   // features (fp32) / k-steps (fp64) per register set, two sets
     const int T2 = wave & 1, q = ((wave >> 1) + blockIdx.x) & (KQ - 1);
     const int ks1 = pout >> 2, kper = (ks1 + KQ - 1) / KQ;
     const int s_lo = q * kper, s_hi = min(s_lo + kper, ks1);
     const int len = s_hi - s_lo;
-    const int ncol = 64 * T2 + 4 * col;
-    const bool nvalid = ncol + 3 < H;
-    const T *wp = W1 + (nvalid ? ncol : 0) + (4L * min(s_lo, ks1 - 1) + kq) * H;   // (an empty range still loads from valid rows)
+    const int flen = FC4 ? 4 * len : len;           // length of the range in set registers
+    const int ncol = FC4 ? 64 * T2 + lane : 64 * T2 + 4 * col;
+    const bool nvalid = FC4 ? ncol < H : ncol + 3 < H;
+    // (an empty range still loads from valid rows)
+    const T *wp = W1 + (nvalid ? ncol : 0) + (4L * min(s_lo, ks1 - 1) + (FC4 ? 0 : kq)) * H;
     struct W1Set {
-        Quad<T> w[U];
+        std::conditional_t<FC4, T, Quad<T>> w[U];
     } fa, fb;
-    auto fc1_issue = [&](int i, W1Set &st) {   // k-steps i .. i + U - 1 of this wave's range (clamped, unconditional)
+    auto fc1_issue = [&](int i, W1Set &st) {   // registers i .. i + U - 1 of this wave's range (clamped, unconditional)
 #pragma unroll
-        for (int u = 0; u < U; u++) st.w[u].load(wp + 4 * H * max(min(i + u, len - 1), 0));
+        for (int u = 0; u < U; u++) {
+            const int k = max(min(i + u, flen - 1), 0);
+            if constexpr (FC4) st.w[u] = wp[(long)H * k];
+            else st.w[u].load(wp + 4 * H * k);
+        }
     };
     fc1_issue(0, fa);
     fc1_issue(U, fb);
@@ -319,7 +328,48 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
     // half T covers neurons 64 T .. 64 T + 63, column c of its j-th tile is neuron 64 T + 4 c + j,
     // i.e. one vector load feeds four tiles.  A row of W1 (400 bytes) is fetched exactly once per
     // workgroup: 256 bytes by a T = 0 wave, 144 by its T = 1 partner.
+    // fp32: the 16-wide tile would be half empty (eight samples), and the product runs at the matrix
+    // pipe's rate, so it goes to v_mfma_f32_4x4x1 (16 independent 4 x 4 x 1 blocks, 8 cycles): a block =
+    // four samples x four neurons x ONE pooled feature.  Lane l supplies W1[p][64 T + l] (a 256-byte
+    // run of the row per load) and pool[l mod 4 + 4 g][p] (sample group g, four features per 16-byte
+    // LDS read) and receives z[4 g + i][64 T + l] in register i: two instructions of 8 cycles per
+    // feature and 64 neurons, where four half-empty 16 x 16 x 4 tiles took 32 cycles per feature.
     {
+        T *zp = rb;   // [KQ][8][TILE_ZN] (the filters are dead)
+        if constexpr (FC4) {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            const T *ap0 = pl + min(lane & 3, ms - 1) * L.pld + 4 * s_lo;
+            const T *ap1 = pl + min((lane & 3) + 4, ms - 1) * L.pld + 4 * s_lo;
+            f4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+            auto fc1_mul = [&](int i, const W1Set &st) {
+#pragma unroll
+                for (int u = 0; u < U; u += 4) {
+                    if (i + u < flen) {   // (the range is whole k-steps: four features)
+                        const V a0 = *reinterpret_cast<const V *>(ap0 + i + u);
+                        const V a1 = *reinterpret_cast<const V *>(ap1 + i + u);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[k], st.w[u + k], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[k], st.w[u + k], acc1, 0, 0, 0);
+                        }
+                    }
+                }
+            };
+            for (int i = 0; i < flen; i += 2 * U) {
+                fc1_mul(i, fa);
+                if (i + 2 * U < flen) fc1_issue(i + 2 * U, fa);
+                fc1_mul(i + U, fb);
+                if (i + 3 * U < flen) fc1_issue(i + 3 * U, fb);
+            }
+            TT(3);
+            if (nvalid) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    if (r < ms) zp[(q * 8 + r) * TILE_ZN + ncol] = acc0[r];
+                    if (4 + r < ms) zp[(q * 8 + 4 + r) * TILE_ZN + ncol] = acc1[r];
+                }
+            }
+        } else {
         const T *ap = pl + min(col, ms - 1) * L.pld + 4 * s_lo + kq;
         typename Mma<T>::acc_t acc[4];
 #pragma unroll
@@ -342,7 +392,6 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
             if (i + 3 * U < len) fc1_issue(i + 3 * U, fb);
         }
         TT(3);
-        T *zp = rb;   // [KQ][8][TILE_ZN] (the filters are dead)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
 #pragma unroll
@@ -350,6 +399,7 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
                 const int sr = Mma<T>::row(lane, r);
                 if (sr < ms && nvalid) zp[(q * 8 + sr) * TILE_ZN + ncol + j] = acc[j][r];
             }
+        }
         }
         lds_barrier();
         for (int e = tid; e < nb * H; e += nt) {
