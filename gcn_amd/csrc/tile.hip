@@ -202,38 +202,73 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
         T t0[16];   // the first 1024 cube elements and the filters: one memory round trip, before any LDS work
 #pragma unroll
         for (int u = 0; u < 16; u++) t0[u] = src[min(u * 64 + lane, d.cube - 1)];
-        constexpr int NWR = (F * K + nt - 1) / nt;
+        // The conv filters as conv_pool_chain wants them (ccnn_device.h: filters 0..15 tap-major, then
+        // the packed tile; the fp32 reference walks the filter backwards in the forward pass only,
+        // gcn_mbgd_fp32.cu:241-243).  fp32, eight waves or more: thread t owns elements t, t + nt, .. of
+        // the IMAGE and fetches the filter value (or a zero) that belongs there, so consecutive lanes
+        // store consecutive words - no zeroing pass, no barrier before the stores, no bank conflicts.
+        // (Owning elements of the FILTERS instead, as the other forms below do, puts the 64 stores of a
+        // wave 16 words apart: two banks, 32-way conflicts, about 2 us of LDS time per tile with 16 waves.)
+        constexpr bool IMG = sizeof(T) == 4 && NWV >= 8;
+        static_assert(LDWK == 16, "the image element -> (tap, filter) split below");
+        constexpr int NWR = IMG ? (WP_LEN + nt - 1) / nt : (F * K + nt - 1) / nt;
         T wreg[NWR];
+        unsigned wok = 0;   // IMG: bit u = element u holds a filter value (else a zero)
 #pragma unroll
-        for (int u = 0; u < NWR; u++) wreg[u] = params[d.off_w0 + min(u * nt + tid, F * K - 1)];   // clamped, unconditional
+        for (int u = 0; u < NWR; u++) {
+            if constexpr (IMG) {
+                const int e = u * nt + tid;
+                int f, kk;
+                if (e < WL_TILE) {
+                    kk = e >> 4;
+                    f = e & 15;
+                } else {
+                    const int x = e - WL_TILE, c = x & 15;
+                    f = 16 + (c & 3);
+                    kk = (x >> 4) - WSTEP * (c >> 2);   // column c = shift c / 4 of filter 16 + c % 4
+                }
+                const bool ok = e < WP_LEN && kk >= 0 && kk < K;
+                wreg[u] = params[d.off_w0 + (ok ? f * K + (FLIP ? K - 1 - kk : kk) : 0)];
+                wok |= (unsigned)ok << u;
+            } else {
+                wreg[u] = params[d.off_w0 + min(u * nt + tid, F * K - 1)];   // clamped, unconditional
+            }
+        }
         constexpr int NW2 = (H * OMAX + nt - 1) / nt;
         T w2r[NW2];
 #pragma unroll
         for (int u = 0; u < NW2; u++) w2r[u] = params[d.off_w2 + min(u * nt + tid, H * no - 1)];
         const T b1r = params[d.off_b1 + min(tid, H - 1)], b2r = params[d.off_b2 + min(tid, no - 1)];
-        for (int e = tid; e < WP_LEN; e += nt) rb[e] = 0;
+        if constexpr (!IMG)
+            for (int e = tid; e < WP_LEN; e += nt) rb[e] = 0;
 #pragma unroll
         for (int u = 0; u < NW2; u++)
             if (u * nt + tid < H * no) w2s[u * nt + tid] = w2r[u];
         if (tid < H) b1s[tid] = b1r;
         if (tid < no) b2s[tid] = b2r;
         TT(11);
-        lds_barrier();
-        TT(12);
-        // filters as conv_pool_chain wants them (ccnn_device.h: filters 0..15 tap-major, then the
-        // packed tile); the fp32 reference walks the filter backwards in the forward pass only
-        // (gcn_mbgd_fp32.cu:241-243)
+        if constexpr (IMG) {
+            TT(12);
 #pragma unroll
-        for (int u = 0; u < NWR; u++) {
-            const int e = u * nt + tid;
-            if (e < F * K) {
-                const int f = e / K, k = e - f * K;
-                const int kk = FLIP ? K - 1 - k : k;
-                if (f < 16) {
-                    rb[kk * LDWK + f] = wreg[u];
-                } else {
+            for (int u = 0; u < NWR; u++) {
+                const int e = u * nt + tid;
+                if (e < WP_LEN) rb[e] = (wok >> u & 1) ? wreg[u] : T(0);
+            }
+        } else {
+            lds_barrier();
+            TT(12);
 #pragma unroll
-                    for (int g = 0; g < 4; g++) rb[WL_TILE + (kk + WSTEP * g) * LDWK + 4 * g + (f - 16)] = wreg[u];
+            for (int u = 0; u < NWR; u++) {
+                const int e = u * nt + tid;
+                if (e < F * K) {
+                    const int f = e / K, k = e - f * K;
+                    const int kk = FLIP ? K - 1 - k : k;
+                    if (f < 16) {
+                        rb[kk * LDWK + f] = wreg[u];
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < 4; g++) rb[WL_TILE + (kk + WSTEP * g) * LDWK + 4 * g + (f - 16)] = wreg[u];
+                    }
                 }
             }
         }
@@ -255,7 +290,9 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
             }
         }
     }
+    TT(14);
     lds_barrier();
+    TT(15);
 
     // FC1 geometry (the product itself comes after the conv phase; its first W1 loads are issued
     // before it).  Every workgroup reads all of W1: its waves' K ranges are dealt in an order rotated

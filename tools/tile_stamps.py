@@ -31,7 +31,7 @@ assert lib.ccnn_debug_tile_ticks(t) == 0
 names = ["stage", "conv+pool", "fc1 K loop", "fc1 reduce", "w1 prefetch", "head", "dpool", "bias", "conv_bwd", "store"]
 print(f"z={z} B={B} {DT.__name__}: " + "  ".join(f"{names[k]}={(t[k + 1] - t[k]) * 10}ns" for k in range(10)),
       f"total={(t[10] - t[0]) * 10}ns")
-print("  stage: small operands stored +%dns, barrier (first loads landed) +%dns, filters scattered +%dns"
-      % tuple((t[k] - t[0]) * 10 for k in (11, 12, 13)))
+print("  stage: small operands stored +%dns, barrier (first loads landed) +%dns, filters scattered +%dns, cube in LDS +%dns, barrier +%dns"
+      % tuple((t[k] - t[0]) * 10 for k in (11, 12, 13, 14, 15)))
 print("  shader clock per phase (GHz): " + "  ".join(
     f"{names[k]}={(t[21 + k] - t[20 + k]) / ((t[k + 1] - t[k]) * 10.0):.2f}" for k in range(10) if t[k + 1] > t[k]))
