@@ -1109,7 +1109,7 @@ __global__ __launch_bounds__(GB_THREADS) void grad_reduce_big(int B, int pout, i
 // that costs the same from 1 to 256 samples (one workgroup per CU) and then grows by the full
 // chain per 256 samples (every workgroup walks all of W1 twice).  The sample-tile kernel's chain is
 // half as long again for one sample but takes up to eight samples per workgroup at little more, and
-// reads W1 twice per TILE.  Measured crossovers fused -> tile: B = 450 (z = 103, fp32), 650
+// reads W1 twice per TILE.  Measured crossovers fused -> tile: B = 257 (z = 103, fp32), 513
 // (z = 200, fp32), 480 (z = 176, fp64).  Where a tile holds so few samples that the batch needs
 // more than one round of workgroups (fp64, or fp32 beyond 200 bands: the LDS holds four samples)
 // the layer kernels win again from about 2000 samples (z = 176, fp64: 180 against 220 us at 2048).
@@ -1132,7 +1132,10 @@ inline StepPath step_path(int B, const ccnn_dims_t &d, TilePlan *plan)
         if (!strcmp(e, "layers")) return StepPath::LAYERS;
         if (!strcmp(e, "batched") || !strcmp(e, "tile")) return fits ? StepPath::TILE : StepPath::LAYERS;
     }
-    const int tile_min_b = (sizeof(T) == 8 || d.z <= 128) ? 512 : 704;
+    // fp32: the fused kernel's time steps up where its workgroups stop fitting the chip at once - past
+    // 256 samples up to 128 bands (35 us at 288 against the tile kernel's 32), past 512 beyond (two
+    // workgroups per CU: 55 us at 512 and 74 at 576 against 57 and 63, 200 bands); fp64 as measured
+    const int tile_min_b = sizeof(T) == 8 ? 512 : d.z <= 128 ? 257 : 513;
     // one round of workgroups, or several rounds of FULL tiles at small band counts (fp32, B = 4096:
     // 110 us against the layer kernels' 120 at z = 103, but 210 against 198 at z = 224)
     const bool rounds_ok = tp.tiles <= 256 || (sizeof(T) == 4 && tp.ms == 8 && d.z <= 128);

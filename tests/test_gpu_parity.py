@@ -321,7 +321,8 @@ def test_mbgd_fused_step_matches_oracle(dtype, z, B, lr, mbgd_path):
             assert np.all(out[d.off_b0:d.off_w1] == 0)
 
 
-@pytest.mark.parametrize("dtype,z,B,lr", [(np.float32, 103, 2045, 0.002),    # full tiles of eight, the last one ragged
+@pytest.mark.parametrize("dtype,z,B,lr", [(np.float32, 103, 301, 0.01),      # the smallest batches of the tile path: two samples per tile, the last one ragged
+                                          (np.float32, 103, 2045, 0.002),    # full tiles of eight, the last one ragged
                                           (np.float32, 200, 1797, 0.002),    # full tiles, delta image in four chunks
                                           (np.float32, 224, 1024, 0.004),    # four samples per tile
                                           (np.float32, 224, 2043, 0.002),    # the largest shape that fits eight samples
