@@ -266,7 +266,12 @@ __device__ __forceinline__ T reduce_scatter16(T (&v)[16], int lane)
 // start at multiples of 16).  In the f32 C/D map a lane holds rows 4q..4q+3, so both
 // members of a pair are in the same lane; in the f64 map it holds rows q, q+4, q+8,
 // q+12 and the partner row lives in lane^16.  put(f, m, value, winning position).
-template <typename Put>
+// WIN = false (callers that drop the winning position: inference): the larger conv output is picked
+// first and activated once.  Bit-identical values - the fp32 act() is monotone non-decreasing over
+// all finite floats (tools/probes/act_monotone.hip checks every pair of neighbouring floats on the
+// hardware), and so is the rounded bias add - for half the exp / rcp work, which on this part runs
+// instead of, not beside, the matrix instructions.
+template <bool WIN = true, typename Put>
 __device__ __forceinline__ void pool_tile(const Mma<float>::acc_t &acc, float bias, int f, bool fvalid, int t0,
                                           int re, int lane, Put put)
 {
@@ -274,6 +279,14 @@ __device__ __forceinline__ void pool_tile(const Mma<float>::acc_t &acc, float bi
 #pragma unroll
     for (int r = 0; r < 4; r += 2) {
         const int t = t0 + 4 * q + r;
+        if (!WIN) {
+            if (fvalid && t < re) {
+                float x = acc[r] + bias;
+                if (t + 1 < re) x = fmaxf(x, acc[r + 1] + bias);
+                put(f, t >> 1, act(x), t);
+            }
+            continue;
+        }
         if (fvalid && t < re) {
             float best = act(acc[r] + bias);
             int bt = t;
@@ -288,7 +301,7 @@ __device__ __forceinline__ void pool_tile(const Mma<float>::acc_t &acc, float bi
         }
     }
 }
-template <typename Put>
+template <bool WIN = true, typename Put>
 __device__ __forceinline__ void pool_tile(const Mma<double>::acc_t &acc, double bias, int f, bool fvalid, int t0,
                                           int re, int lane, Put put)
 {
@@ -494,7 +507,7 @@ __device__ __forceinline__ void lds_barrier()
 __host__ __device__ inline int conv_chains(int re) { return conv_mtiles(re) + (((re - 1) >> 2) >> 4) + 1; }
 
 // Chain c of a sample (c < conv_chains(re)) by one wave.
-template <typename T, typename Put>
+template <typename T, bool WIN = true, typename Put>
 __device__ __forceinline__ void conv_pool_chain(const T *cube, const T *wl, int re, int c, T bias0, T biasx, int lane,
                                                 Put put)
 {
@@ -504,7 +517,7 @@ __device__ __forceinline__ void conv_pool_chain(const T *cube, const T *wl, int 
     if (c < mt) {
         const T *ap = cube + WSTEP * (c * 16 + col) + kq;
         const typename Mma<T>::acc_t acc = mma_chain<T, KSTEPS0>(ap, bp0);
-        pool_tile(acc, bias0, col, true, c * 16, re, lane, put);
+        pool_tile<WIN>(acc, bias0, col, true, c * 16, re, lane, put);
         return;
     }
     const int tau = c - mt, jmax = (re - 1) >> 2;
@@ -530,7 +543,7 @@ __device__ __forceinline__ void conv_pool_chain(const T *cube, const T *wl, int 
 }
 
 // Position tiles t0 .. t0 + NT - 1 of filters 0..15 as one group of chains (mma_chain_n).
-template <typename T, int NT, typename Put>
+template <typename T, int NT, bool WIN = true, typename Put>
 __device__ __forceinline__ void conv_pool_group(const T *cube, const T *wl, int re, int t0, T bias0, int lane, Put put)
 {
     const int col = lane & 15, kq = lane >> 4;
@@ -540,26 +553,26 @@ __device__ __forceinline__ void conv_pool_group(const T *cube, const T *wl, int 
     typename Mma<T>::acc_t acc[NT];
     mma_chain_n<T, KSTEPS0, NT>(ap, wl + kq * LDWK + col, acc);
 #pragma unroll
-    for (int t = 0; t < NT; t++) pool_tile(acc[t], bias0, col, true, (t0 + t) * 16, re, lane, put);
+    for (int t = 0; t < NT; t++) pool_tile<WIN>(acc[t], bias0, col, true, (t0 + t) * 16, re, lane, put);
 }
 
 // All chains of one sample by one wave: the position tiles of filters 0..15 in groups of three
 // (or two) that share the filter fragments, then the packed-tile chains.
-template <typename T, typename Put>
+template <typename T, bool WIN = true, typename Put>
 __device__ __forceinline__ void conv_pool_wave(const T *cube, const T *wl, int re, T bias0, T biasx, int lane,
                                                Put put)
 {
     const int mt = conv_mtiles(re), nc = conv_chains(re);
     int t = 0;
     while (mt - t >= 3 && mt - t != 4) {
-        conv_pool_group<T, 3>(cube, wl, re, t, bias0, lane, put);
+        conv_pool_group<T, 3, WIN>(cube, wl, re, t, bias0, lane, put);
         t += 3;
     }
     while (mt - t >= 2) {
-        conv_pool_group<T, 2>(cube, wl, re, t, bias0, lane, put);
+        conv_pool_group<T, 2, WIN>(cube, wl, re, t, bias0, lane, put);
         t += 2;
     }
-    for (int c = t; c < nc; c++) conv_pool_chain<T>(cube, wl, re, c, bias0, biasx, lane, put);
+    for (int c = t; c < nc; c++) conv_pool_chain<T, WIN>(cube, wl, re, c, bias0, biasx, lane, put);
 }
 
 // Stages the 20 x 171 filters as conv_pool_wave wants them (zero taps and columns included), by a

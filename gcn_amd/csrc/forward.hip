@@ -211,7 +211,7 @@ __global__ __launch_bounds__(64 * CONV_MAXWAVES) void conv_pool_fwd(const T *__r
         if (PREFETCH && r_nxt >= 0) issue(r_nxt, ib);      // next sample's loads fly during the MFMAs
         int inext = 0;
         if (SCENE) inext = load_idx(r_nn);                 // and the list of the sample after it
-        conv_pool_wave<T>(cube, wl, re, bias0, biasx, lane, [&](int f, int m, T v, int bt) {
+        conv_pool_wave<T, TRAIN>(cube, wl, re, bias0, biasx, lane, [&](int f, int m, T v, int bt) {
             pl[f * mre + m] = v;
             if (TRAIN) pxl[f * mre + m] = (unsigned char)(bt - 2 * m);
         });
