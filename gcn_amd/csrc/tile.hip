@@ -604,7 +604,6 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
     // cube, 11 tap tiles.  Every wave builds the delta image of its own sample; an image covers kc
     // k-steps of positions at a time (nch chunks) where a whole one would not fit.
     T *out = part + (long)blockIdx.x * (F * K + F);
-    const int q64 = 64 / mre, r64 = 64 - q64 * mre;
     if (ms > TILE_ACC_MS) {
         // Full tiles.  Filters 0..15 as 16 x 16 x 4 products against the 11 tap tiles; filters 16..19
         // (fp32) on the 16-block 4 x 4 x 1 instruction instead of a second 16-wide tile with twelve
@@ -647,8 +646,11 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
             if (PAIR) lds_barrier();
             else wave_sync();
             if (part) {
-                for (int p = lane + 64 * hf; p < pout; p += 64 * NBW) {
-                    const int f = p / mre, m = p - f * mre;
+                // consecutive lanes take consecutive FILTERS of one pooled position: their stores fall on
+                // consecutive words of the position-major image (lanes that walk the positions of one
+                // filter store 32 or 48 words apart - two banks), and the split is by a constant
+                for (int i = lane + 64 * hf; i < pout; i += 64 * NBW) {
+                    const int m = i / F, f = i - m * F, p = f * mre + m;
                     const int tt = 2 * m + (int)pxs[p] - t_lo;
                     if (tt >= 0 && tt < 4 * L.kc) dl[(f >> 4) * L.ldd + tt * LDWK + (f & 15)] = pls[p];
                 }
@@ -777,16 +779,10 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
             if (mine) {
                 for (int e = lane; e < 2 * L.ldd; e += 64) dl[e] = 0;
                 wave_sync();
-                int f = lane / mre, m = lane - f * mre;   // feature p = lane + 64 i as (filter, pooled position), stepped
-                for (int p = lane; p < pout; p += 64) {
+                for (int i = lane; i < pout; i += 64) {   // consecutive lanes: consecutive filters of one pooled position (as above)
+                    const int m = i / F, f = i - m * F, p = f * mre + m;
                     const int tt = 2 * m + (int)pxr[p] - t_lo;
                     if (tt >= 0 && tt < 4 * L.kc) dl[(f >> 4) * L.ldd + tt * LDWK + (f & 15)] = plr[p];
-                    f += q64;
-                    m += r64;
-                    if (m >= mre) {
-                        m -= mre;
-                        f++;
-                    }
                 }
             }
             lds_barrier();   // every sample's image is complete
