@@ -28,6 +28,7 @@ from gcn_amd import lib as L  # noqa: E402
 from gcn_amd import ops, prep  # noqa: E402
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3     # MI355X dense f32 MFMA
+PEAK_FP64_MATRIX_TFLOPS = 78.6      # MI355X dense f64 MFMA
 PEAK_HBM_GBS = 8000.0               # HBM3E spec
 SEED_BASE = 20240
 WORKLOAD_CONFIG = {"ksc": 2, "indian_pines": 3, "pavia_u": 4, "aviris": 5}
@@ -61,23 +62,47 @@ def kernel_work(d, z):
     }
 
 
+KERNEL_SOURCES = ("mbgd.hip", "tile.hip", "forward.hip", "ccnn_device.h")   # what the training kernels are built from
+
+
+def kernel_source_digest():
+    """sha256 over the sources of the training kernels: identifies the build a PMC pass profiled."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "gcn_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def committed_traffic(workload, batch, kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc cannot
-    run inside this process); None when no pass was recorded for this workload and batch."""
+    """(HBM bytes per launch of `kernel`, where the figure comes from).  The bytes are those of the
+    committed PMC passes (rocprofv3 --pmc cannot run inside this process): None when no pass was
+    recorded for this workload and batch, and None - with the reason - when the kernels' sources
+    have changed since the pass (tools/make_traffic.py stamps their digest into the file)."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            for rec in json.load(f)["records"]:
-                if (rec["workload"], rec["batch"], rec["kernel"]) == (workload, batch, kernel):
-                    return rec["hbm_bytes_per_launch"]
+            doc = json.load(f)
+        for rec in doc["records"]:
+            if (rec["workload"], rec["batch"], rec["kernel"]) == (workload, batch, kernel):
+                where = f"committed {doc.get('summaries', 'profiles/')} (profiles/traffic.json), kernels @{doc.get('kernel_source_digest')}"
+                try:
+                    now = kernel_source_digest()
+                except OSError:
+                    now = None
+                if doc.get("kernel_source_digest") != now:
+                    return None, f"stale: {where}, sources now @{now}"
+                return rec["hbm_bytes_per_launch"], where
     except (OSError, KeyError, ValueError):
         pass
-    return None
+    return None, "no PMC pass recorded for this workload and batch"
 
 
-def kernel_rows(rep, d, z, pixels, passes=None, world=1):
+def kernel_rows(rep, d, z, pixels, passes=None, world=1, es=4):
     """Per-kernel table from the library's event timings: average duration, achieved rate on the
-    kernel's algorithmic work and its fraction of the peak that bounds it."""
+    kernel's algorithmic work and its fraction of the peak that bounds it (es: element size)."""
     work = kernel_work(d, z)
+    peak_mfma = PEAK_FP32_MATRIX_TFLOPS if es == 4 else PEAK_FP64_MATRIX_TFLOPS
     rows = {}
     for name, (ms, cnt) in rep.items():
         if name not in work or cnt == 0 or (work[name][1] is not None and name not in pixels):
@@ -85,13 +110,13 @@ def kernel_rows(rep, d, z, pixels, passes=None, world=1):
         bound, per_px = work[name]
         if per_px is None:
             factor = {"allreduce_apply": 3.0 + 2.0 * world}.get(name, 3.0)
-            units = factor * d.nparams * 4 * cnt
+            units = factor * d.nparams * es * cnt
         else:
             # a pass over n pixels may be several launches (the library works through its workspace in chunks)
-            units = per_px * pixels[name] * (passes.get(name, cnt) if passes else cnt)
+            units = per_px * (es / 4.0 if bound == "hbm" else 1.0) * pixels[name] * (passes.get(name, cnt) if passes else cnt)
         tot_s = ms * 1e-3
         if bound == "mfma":
-            ach, peak, unit = units / tot_s / 1e12, PEAK_FP32_MATRIX_TFLOPS, "TFLOP/s"
+            ach, peak, unit = units / tot_s / 1e12, peak_mfma, "TFLOP/s"
         else:
             ach, peak, unit = units / tot_s / 1e9, PEAK_HBM_GBS, "GB/s"
         rows[name] = {"avg_us": round(ms / cnt * 1e3, 3), "launches": cnt, "bound": bound,
@@ -110,8 +135,9 @@ def dominant(rows, workload, B):
         return None
     dom = max(train_k, key=lambda k: rows[k]["avg_us"])
     k = rows[dom]
+    traffic, source = committed_traffic(workload, B, dom)
     return {"kernel": dom, "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"], "unit": k["unit"],
-            "frac": k["frac"], "traffic": committed_traffic(workload, B, dom), "avg_us": k["avg_us"]}
+            "frac": k["frac"], "traffic": traffic, "traffic_source": source, "avg_us": k["avg_us"]}
 
 
 def timed_steps(fn, n):
@@ -124,17 +150,19 @@ def timed_steps(fn, n):
 
 
 def train_rate(params_h, cubes, onehot_d, z, B, steps, workload, profile=True):
-    """fp32 MBGD steps of B samples over `cubes` (already on the device): pixels/s, and the
-    per-kernel table of the same steps.  The step size is scaled with 128/B (plain-sum update)."""
+    """MBGD steps of B samples over `cubes` (already on the device) in the precision of params_h:
+    pixels/s, and the per-kernel table of the same steps.  fp32: the step size is scaled with 128/B
+    (plain-sum update); fp64: the reference's 0.5 (mean over the batch)."""
     d = L.dims(z)
     n = cubes.shape[0]
     nb = n // B
     if nb < 1:
         return None
+    es = params_h.dtype.itemsize
     p = torch.from_numpy(params_h).to(cubes.device)
     ws = ops.Workspace(cubes.device)
     lv = torch.zeros((nb, B), dtype=torch.float64, device=cubes.device)
-    lr = 0.04 * min(1.0, 128.0 / B)
+    lr = 0.04 * min(1.0, 128.0 / B) if es == 4 else 0.5
 
     def step(i):
         b = i % nb
@@ -144,7 +172,7 @@ def train_rate(params_h, cubes, onehot_d, z, B, steps, workload, profile=True):
     dt = timed_steps(step, steps)
     assert torch.isfinite(p).all(), "training diverged"
     out = {"batch": B, "train_pixels_per_s": round(B / dt, 1), "us_per_step": round(dt * 1e6, 2),
-           "path": STEP_PATHS.get(L.load().ccnn_mbgd_path(B, z, 4), "?")}
+           "path": STEP_PATHS.get(L.load().ccnn_mbgd_path(B, z, es), "?")}
     if profile:
         L.profile_enable(True)
         psteps = min(steps, 100)
@@ -152,8 +180,8 @@ def train_rate(params_h, cubes, onehot_d, z, B, steps, workload, profile=True):
             step(i)
         torch.cuda.synchronize()
         L.profile_enable(False)
-        rows = kernel_rows(L.profile_report(), d, z, {k: B for k in TRAIN_KERNELS})
-        out["roofline"] = dominant(rows, workload, B)
+        rows = kernel_rows(L.profile_report(), d, z, {k: B for k in TRAIN_KERNELS}, es=es)
+        out["roofline"] = dominant(rows, workload if es == 4 else workload + "_f64", B)
         out["kernels"] = {k: {"avg_us": v["avg_us"], "frac": v["frac"]} for k, v in rows.items()}
     return out
 
@@ -187,6 +215,7 @@ def gather_call_rate(scene_d, idx_d, x, y, z, out, reps=5):
     dt1 = (time.perf_counter() - t) / reps
     return {"us_per_call": round(dt * 1e6, 1), "pixels": n, "achieved": round(byts / dt / 1e9, 1), "peak": PEAK_HBM_GBS,
             "unit": "GB/s", "frac": round(byts / dt / 1e9 / PEAK_HBM_GBS, 4),
+            "kernel": "gather_dense (tiles)" if plan.dense else "gather_tile (ordered list)",
             "what": "ccnn_gather_planned_f32, wall clock of the whole call (the list's order comes from one ccnn_gather_plan)",
             "plan_us_once": round(t_plan * 1e6, 1),
             "one_shot": {"us_per_call": round(dt1 * 1e6, 1), "frac": round(byts / dt1 / 1e9 / PEAK_HBM_GBS, 4),
@@ -240,7 +269,24 @@ def workload_report(name, dev, full=True):
     idx_d = torch.from_numpy(np.ascontiguousarray(tr9[:n_train])).to(dev)
     cubes = torch.empty((n_train, 9 * z), dtype=torch.float32, device=dev)
     out = {"scene": f"{x}x{y}x{z}", "labelled_pixels": int(len(di)), "train_pixels_used": int(n_train)}
-    out["gather_call"] = gather_call_rate(scene_d, idx_d, x, y, z, cubes)
+    if name == "aviris":
+        # config 5's gather: the scene is fully labelled, so a rank gathers a solid block of it - here
+        # 600 whole columns (1 228 800 pixels, 9.9 GB of cubes, output offsets past 2^31 elements) in
+        # the shuffled order of the sample list; the plan picks the LDS-staged tile kernel for it
+        blk = np.concatenate([tr9, te9])
+        blk = blk[(blk[:, 4] // x) < 600]
+        blk = blk[np.random.default_rng(SEED_BASE + 5).permutation(len(blk))]
+        blk_d = torch.from_numpy(np.ascontiguousarray(blk)).to(dev)
+        big = torch.empty((len(blk), 9 * z), dtype=torch.float32, device=dev)
+        out["gather_call"] = gather_call_rate(scene_d, blk_d, x, y, z, big, reps=3)
+        out["gather_call"]["list"] = "600 whole columns of the fully labelled scene, shuffled"
+        del big, blk_d, blk
+        torch.cuda.empty_cache()
+        # the first 65 536 samples of the shuffled training list: a 1.5 % sparse sample of the scene
+        # (neighbouring samples share no rows) - what the training-rate lines below run on
+        out["gather_call_sparse_sample"] = gather_call_rate(scene_d, idx_d, x, y, z, cubes)
+    else:
+        out["gather_call"] = gather_call_rate(scene_d, idx_d, x, y, z, cubes)
     oh_d = torch.from_numpy(np.ascontiguousarray(onehot[:n_train])).to(dev)
     for B in (128, 2048):
         r = train_rate(params_h, cubes, oh_d, z, B, 300 if B == 128 else 100, name, profile=False)
@@ -278,6 +324,8 @@ def workload_report(name, dev, full=True):
         ops.sgd(p64, c64, o64, 0, ns, z, 0.008, sl, workspace=sws)
         torch.cuda.synchronize()
         out["sgd_fp64_pixels_per_s"] = round(ns / (time.perf_counter() - t), 1)
+        # the reference's canonical trainer on its own scene shape: fp64 MBGD, B = 100 (gcn_mbgd_fp64.cu)
+        out["mbgd_fp64_b100"] = train_rate(prep.init_params(z, np.float64, 100 * d.pout), c64, o64, z, 100, 200, name)
     return out
 
 
@@ -385,7 +433,7 @@ def main():
     # every rank), "instep_owner" (the same with the sums meeting at an owner rank that sends the total
     # round: fewer bytes per link, one more hop), "standalone" (gradient, then the library's exchange +
     # update kernel) or "rccl" (gradient, RCCL all-reduce, update)
-    mode = ("instep_owner" if world >= 4 else "instep") if comm is not None else "rccl"
+    mode = "instep" if comm is not None else "rccl"     # the library's default form; the warm-up below times the others
 
     def set_mode(m):
         nonlocal mode
@@ -498,6 +546,20 @@ def main():
     log(f"timing {args.steps} steps, mode {mode}")
     dt = timed(args.steps, args.warmup)
     train_pps = world * B * args.steps / dt
+    # how much a single step's time scatters around that mean: the same steps again (untimed for
+    # `value`), each bracketed by events on the launch stream (this rank's GPU only)
+    nsp = max(20, min(args.steps, 200))
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(nsp + 1)]
+    fence()
+    evs[0].record()
+    for i in range(nsp):
+        step(args.warmup + i)
+        evs[i + 1].record()
+    fence()
+    per = np.array([evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(nsp)])
+    spread = {"steps": nsp, "median_us": round(float(np.median(per)), 2), "p10_us": round(float(np.percentile(per, 10)), 2),
+              "p90_us": round(float(np.percentile(per, 90)), 2), "max_us": round(float(per.max()), 2),
+              "what": "per-step intervals between events recorded after each step of a second, untimed pass"}
     log(f"timed region done: {dt / args.steps * 1e6:.2f} us/step")
     assert torch.isfinite(params).all(), "training diverged"
     replicas_identical = True
@@ -584,27 +646,16 @@ def main():
         assert torch.isfinite(p64).all()
         del cubes64
 
-    # ---- fp64 MBGD (the reference's canonical build, gcn_mbgd_fp64.cu: B = 100) on the same cubes, rank 0
-    mbgd64_pps = None
+    # ---- fp64 MBGD (the reference's canonical build, gcn_mbgd_fp64.cu: B = 100) on the same cubes, rank 0:
+    # rate, and its dominant kernel against the fp64 matrix peak
+    mbgd64 = None
     if rank == 0:
         B64 = 100
         n64 = min(slice_len // B64, 40)
         c64 = cubes[:n64 * B64].double()
         o64 = onehot_d[:n64 * B64].contiguous()
-        p64 = torch.from_numpy(prep.init_params(z, np.float64, B64)).to(dev)
-        l64 = torch.zeros(B64, dtype=torch.float64, device=dev)
-        w64 = ops.Workspace(dev)
-        for i in range(n64):
-            ops.mbgd_step(p64, c64, o64, i * B64, B64, z, 0.5, loss_values=l64, workspace=w64)
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        for r in range(10):
-            for i in range(n64):
-                ops.mbgd_step(p64, c64, o64, i * B64, B64, z, 0.5, loss_values=l64, workspace=w64)
-        torch.cuda.synchronize()
-        mbgd64_pps = 10 * n64 * B64 / (time.perf_counter() - t2)
-        assert torch.isfinite(p64).all()
-        del c64, p64
+        mbgd64 = train_rate(prep.init_params(z, np.float64, B64 * d.pout), c64, o64, z, B64, 400, args.workload)
+        del c64
 
     # ---- per-kernel timing (HIP events on the launch stream, recorded inside the library):
     # the same training steps, one inference pass and one gather of the training list
@@ -679,6 +730,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 5),
+            "step_spread": spread,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -698,7 +750,11 @@ def main():
             "infer_from_scene_pixels_per_s": round(infer_scene_pps, 1),
             "infer_full_scene_pixels_per_s": round(infer_full_pps, 1),
             "sgd_fp64_pixels_per_s": round(sgd_pps, 1),
-            "mbgd_fp64_b100_pixels_per_s": round(mbgd64_pps, 1),
+            "mbgd_fp64_b100_pixels_per_s": mbgd64["train_pixels_per_s"],
+            "by_dtype": {"f64": {args.workload: mbgd64,
+                                 **({"ksc": by_workload["ksc"].get("mbgd_fp64_b100")} if by_workload and "ksc" in by_workload else {}),
+                                 "what": "fp64 MBGD, B = 100 (the reference's canonical trainer); roofline: dominant kernel "
+                                         "against the 78.6 TFLOP/s fp64 matrix peak, from the dispatch events"}},
             "roofline": roof,
             "cpu_baseline": cpu,
             "kernels": kernels,

@@ -697,13 +697,23 @@ int mat_stream(const std::string &spec)
     }
     const size_t c2 = spec.find(':', c1 + 1);
     const std::string file = spec.substr(0, c1), var = spec.substr(c1 + 1, c2 == std::string::npos ? c2 : c2 - c1 - 1);
-    const size_t chunk = c2 == std::string::npos ? (size_t)1 << 20 : (size_t)atol(spec.c_str() + c2 + 1);
+    long chunk_arg = 1L << 20;
+    if (c2 != std::string::npos) {
+        char *end = nullptr;
+        chunk_arg = strtol(spec.c_str() + c2 + 1, &end, 10);
+        if (end == spec.c_str() + c2 + 1 || *end != '\0' || chunk_arg <= 0) {   // not a number, zero or negative
+            fprintf(stderr, "--mat-stream=FILE:VAR[:CHUNK]: CHUNK must be a positive count of values\n");
+            return 1;
+        }
+    }
     matio::Stream st;
     std::string err;
     if (!st.open(file, var, err)) {
         fprintf(stderr, "%s\n", err.c_str());
         return 1;
     }
+    size_t chunk = (size_t)chunk_arg;
+    if (chunk > st.numel()) chunk = st.numel() ? st.numel() : 1;   // never a buffer larger than the variable
     double sum = 0;
     std::vector<float> f32(st.is_single() ? chunk : 0);
     std::vector<double> f64(st.is_single() ? 0 : chunk);

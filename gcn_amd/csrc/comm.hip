@@ -215,11 +215,12 @@ int ccnn_comm_create(int world, int rank, long max_elems, int elem_size, ccnn_co
     d.world = world;
     d.rank = rank;
     d.spin_ticks = COMM_SPIN_TICKS;
-    // In-step exchange: with four or more ranks a workgroup's sums go to one owner rank, who adds
-    // them and sends the total round - a quarter (8 ranks) of the bytes per link of everybody
-    // writing to everybody, for one more hop.  CCNN_COMM_EXCHANGE=direct|owner overrides;
-    // ccnn_comm_set_exchange changes it later.
-    d.via_owner = world >= 4;
+    // In-step exchange: every rank writes to every rank (one hop).  The other form - a workgroup's
+    // sums go to one owner rank, who adds them and sends the total round: a quarter (8 ranks) of the
+    // bytes per link for one more hop - has only ever run with ranks sharing one GPU, so it is
+    // opt-in (CCNN_COMM_EXCHANGE=owner, or ccnn_comm_set_exchange) until a run over xGMI shows it
+    // faster; bench.py times both during its warm-up and keeps the faster one.
+    d.via_owner = 0;
     if (const char *ex = getenv("CCNN_COMM_EXCHANGE")) {
         if (!strcmp(ex, "direct")) d.via_owner = 0;
         if (!strcmp(ex, "owner")) d.via_owner = 1;

@@ -1121,17 +1121,33 @@ constexpr int BATCHED_SPLIT_ROWS = 256;     // up to here one thread of grad_red
 // CCNN_MBGD_PATH=fused|batched|tile|layers overrides the choice by batch size (tests run every
 // path on the same inputs; "batched" = whatever a large batch would take).
 enum class StepPath { FUSED, TILE, LAYERS };
+// The two test switches, read ONCE per entry-point call (tests flip them inside one process, so they
+// cannot be latched at load time; a host that changes its environment while a call is in progress
+// on another thread gets either value).
+struct StepEnv {
+    int path;    // -1: the library chooses; else a StepPath, or 3 = "whatever a large batch would take"
+    int waves;   // CCNN_TILE_WAVES (0: default)
+    bool operator==(const StepEnv &o) const { return path == o.path && waves == o.waves; }
+};
+inline StepEnv step_env()
+{
+    StepEnv e = {-1, tile_waves_env()};
+    if (const char *s = getenv("CCNN_MBGD_PATH")) {
+        if (!strcmp(s, "fused")) e.path = (int)StepPath::FUSED;
+        else if (!strcmp(s, "layers")) e.path = (int)StepPath::LAYERS;
+        else if (!strcmp(s, "batched") || !strcmp(s, "tile")) e.path = 3;
+    }
+    return e;
+}
 template <typename T>
-inline StepPath step_path(int B, const ccnn_dims_t &d, TilePlan *plan)
+inline StepPath step_path(int B, const ccnn_dims_t &d, TilePlan *plan, const StepEnv &env)
 {
     TilePlan tp = {};
-    const bool fits = tile_plan<T>(B, d, &tp);
+    const bool fits = tile_plan_waves<T>(B, d, env.waves, &tp);
     if (plan && fits) *plan = tp;
-    if (const char *e = getenv("CCNN_MBGD_PATH")) {
-        if (!strcmp(e, "fused")) return StepPath::FUSED;
-        if (!strcmp(e, "layers")) return StepPath::LAYERS;
-        if (!strcmp(e, "batched") || !strcmp(e, "tile")) return fits ? StepPath::TILE : StepPath::LAYERS;
-    }
+    if (env.path == (int)StepPath::FUSED) return StepPath::FUSED;
+    if (env.path == (int)StepPath::LAYERS) return StepPath::LAYERS;
+    if (env.path == 3) return fits ? StepPath::TILE : StepPath::LAYERS;
     // fp32: the fused kernel's time steps up where its workgroups stop fitting the chip at once - past
     // 256 samples up to 128 bands (35 us at 288 against the tile kernel's 32), past 512 beyond (two
     // workgroups per CU: 55 us at 512 and 74 at 576 against 57 and 63, 200 bands); fp64 as measured
@@ -1141,6 +1157,34 @@ inline StepPath step_path(int B, const ccnn_dims_t &d, TilePlan *plan)
     const bool rounds_ok = tp.tiles <= 256 || (sizeof(T) == 4 && tp.ms == 8 && d.z <= 128);
     if (fits && B >= tile_min_b && rounds_ok) return StepPath::TILE;
     return B >= BATCHED_MIN_B ? StepPath::LAYERS : StepPath::FUSED;
+}
+// What a batch of B takes, worked out once per (B, geometry, T, switches) and remembered: a training
+// loop asks on every step, and the search over tile shapes is a few hundred layout computations.
+struct StepChoice {
+    StepPath path;
+    TilePlan plan;   // path == TILE
+};
+template <typename T>
+inline StepChoice step_choice(int B, const ccnn_dims_t &d, const StepEnv &env)
+{
+    struct Entry {
+        int B, z, classes;
+        StepEnv env;
+        StepChoice c;
+    };
+    constexpr int N = 8;
+    thread_local Entry cache[N];
+    thread_local int used = 0, next = 0;
+    for (int i = 0; i < used; i++) {
+        const Entry &e = cache[i];
+        if (e.B == B && e.z == d.z && e.classes == d.n_classes && e.env == env) return e.c;
+    }
+    StepChoice c = {};
+    c.path = step_path<T>(B, d, &c.plan, env);
+    cache[next] = Entry{B, d.z, d.n_classes, env, c};
+    next = (next + 1) % N;
+    if (used < N) used++;
+    return c;
 }
 // Two workgroups per sample in the fused kernel: while both halves of every sample fit the device
 // at once, one workgroup per CU (CCNN_FB_SPLIT=0|1 overrides: diagnostics and tests).
@@ -1184,14 +1228,14 @@ struct MbgdWs {
     {
         return path == StepPath::TILE ? tp.tiles : B < BATCHED_MAX_PARTIALS ? B : BATCHED_MAX_PARTIALS;
     }
-    static size_t bytes(int B, const ccnn_dims_t &d)
+    static size_t bytes(int B, const ccnn_dims_t &d, const StepChoice &sc)
     {
         size_t b = 0;
         b += align_up((size_t)B * d.pout * sizeof(T));          // pool
         b += 2 * align_up((size_t)B * H * sizeof(T));           // a1, d1
         b += 2 * align_up((size_t)B * d.n_classes * sizeof(T));   // d2, probs
-        TilePlan tp;
-        const StepPath path = step_path<T>(B, d, &tp);
+        const StepPath path = sc.path;
+        const TilePlan &tp = sc.plan;
         if (path == StepPath::FUSED) {
             b += align_up((size_t)B * (F * K + F) * sizeof(T));     // per-sample conv gradient tiles
         } else {
@@ -1206,7 +1250,7 @@ struct MbgdWs {
         }
         return b;
     }
-    MbgdWs(void *ws, int B, const ccnn_dims_t &d)
+    MbgdWs(void *ws, int B, const ccnn_dims_t &d, const StepChoice &sc)
     {
         Carver c(ws);
         pool = c.take<T>((size_t)B * d.pout);
@@ -1217,7 +1261,8 @@ struct MbgdWs {
         dp = gsum = nullptr;
         px = nullptr;
         ctr = nullptr;
-        path = step_path<T>(B, d, &plan);
+        path = sc.path;
+        plan = sc.plan;
         if (path == StepPath::FUSED) {
             slab = c.take<T>((size_t)B * (F * K + F));
         } else {
@@ -1354,8 +1399,9 @@ int mbgd_impl(const T *params, const T *cubes, const int *onehot, long first, in
     if (make_dims(z, &d)) return CCNN_E_INVALID;
     if (!params || !cubes || !onehot || !loss_values || !ws || B <= 0 || first < 0) return CCNN_E_INVALID;
     if (!grad && !upd.params) return CCNN_E_INVALID;
-    if (ws_bytes < MbgdWs<T>::bytes(B, d)) return CCNN_E_WORKSPACE;
-    MbgdWs<T> w(ws, B, d);
+    const StepChoice sc = step_choice<T>(B, d, step_env());
+    if (ws_bytes < MbgdWs<T>::bytes(B, d, sc)) return CCNN_E_WORKSPACE;
+    MbgdWs<T> w(ws, B, d, sc);
     if (w.path != StepPath::FUSED) return mbgd_batched<T, FLIP>(params, cubes, onehot, first, B, z, d, grad, upd, loss_values, probs, w, st, cm);
     const FusedLayout L = fused_layout<T>(d.re, d.mre);
     // two workgroups per sample while that still fits the chip in one round (one workgroup per CU)
@@ -1426,14 +1472,17 @@ size_t ccnn_mbgd_workspace_bytes(int B, int z, int elem_size)
 {
     ccnn_dims_t d;
     if (make_dims(z, &d) || B <= 0) return 0;
-    return elem_size == 8 ? MbgdWs<double>::bytes(B, d) : MbgdWs<float>::bytes(B, d);
+    const StepEnv env = step_env();
+    return elem_size == 8 ? MbgdWs<double>::bytes(B, d, step_choice<double>(B, d, env))
+                          : MbgdWs<float>::bytes(B, d, step_choice<float>(B, d, env));
 }
 
 int ccnn_mbgd_path(int B, int z, int elem_size)
 {
     ccnn_dims_t d;
     if (make_dims(z, &d) || B <= 0 || (elem_size != 4 && elem_size != 8)) return CCNN_E_INVALID;
-    return (int)(elem_size == 8 ? step_path<double>(B, d, nullptr) : step_path<float>(B, d, nullptr));
+    const StepEnv env = step_env();
+    return (int)(elem_size == 8 ? step_choice<double>(B, d, env).path : step_choice<float>(B, d, env).path);
 }
 
 int ccnn_mbgd_grad_f32(const float *params, const float *cubes, const int *onehot, long first, int B,
@@ -1470,13 +1519,17 @@ int ccnn_mbgd_step_noalloc_f32(float *params, const float *cubes, const int *one
 {
     ccnn_dims_t d;
     if (make_dims(z, &d) || !params || B <= 0) return CCNN_E_INVALID;
-    if (MbgdWs<float>::bytes(B, d) > (size_t)CCNN_NOALLOC_SCRATCH_BYTES) return CCNN_E_SCRATCH;
+    if (MbgdWs<float>::bytes(B, d, step_choice<float>(B, d, step_env())) > (size_t)CCNN_NOALLOC_SCRATCH_BYTES) return CCNN_E_SCRATCH;
     void *ws = nullptr;
     if (int e = scratch_on_current_device(&ws)) return e;
-    // every row of the scratch a step reads is written by the same step first (pool, a1, d1, d2 and
-    // the conv-gradient tiles by sample_fwd_bwd, for exactly the B rows grad_reduce then sums), so
-    // nothing has to be cleared between calls; what an earlier, larger call left beyond row B is
-    // never read
+    // Every row of the scratch a step reads is written by the same step first, on every path, so
+    // nothing has to be cleared between calls and what an earlier call left elsewhere is never
+    // read: the fused kernel writes pool, a1, d1, d2 and one conv-gradient row for exactly the B
+    // samples grad_reduce then sums; the sample-tile kernel writes the same per-sample rows and one
+    // conv-gradient partial per TILE (a ragged last tile included), and grad_reduce_big sums exactly
+    // those `tiles` rows; the layer kernels zero their work counters inside their own launches.
+    // The regions' offsets move with B (MbgdWs carves them in order), which is harmless for the
+    // same reason.
     UpdateRule<float> upd{params, lr, 0, d.off_b0, d.off_w1};
     return mbgd_impl<float, true>(params, cubes, onehot, first, B, z, nullptr, upd, loss_values, nullptr, ws,
                                   (size_t)CCNN_NOALLOC_SCRATCH_BYTES, (hipStream_t)stream);

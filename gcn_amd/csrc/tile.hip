@@ -96,18 +96,23 @@ __host__ __device__ inline TileLayout tile_layout(int re, int mre, int nwv, int 
 
 // Waves per workgroup to try first.  Sixteen (four per SIMD, 128 registers each) for full fp32 tiles:
 // two waves share a sample's conv chains and its conv-gradient products - 45.9 -> 43.1 us at 2048
-// samples of 103 bands, 82 -> 76 us at 200 bands (CCNN_TILE_WAVES=8|16 overrides: tests run both).
+// samples of 103 bands, 82 -> 76 us at 200 bands.  forced_waves = 8 | 16 overrides (the test switch
+// CCNN_TILE_WAVES, read by the caller once per call: tests run both), anything else: the default.
 template <typename T>
-inline int tile_max_waves(int ms)
+inline int tile_max_waves(int ms, int forced_waves)
 {
     if (sizeof(T) != 4 || ms <= TILE_ACC_MS) return 8;
+    return forced_waves == 8 || forced_waves == 16 ? forced_waves : TILE_DEFAULT_WAVES;
+}
+
+int tile_waves_env()
+{
     const char *e = getenv("CCNN_TILE_WAVES");
-    const int forced = e ? atoi(e) : 0;
-    return forced == 8 || forced == 16 ? forced : TILE_DEFAULT_WAVES;
+    return e ? atoi(e) : 0;
 }
 
 template <typename T>
-bool tile_plan(int B, const ccnn_dims_t &d, TilePlan *out)
+bool tile_plan_waves(int B, const ccnn_dims_t &d, int forced_waves, TilePlan *out)
 {
     // samples per tile: enough to cover the batch with one workgroup per compute unit (256 on the
     // part this library is built for), at most one per wave
@@ -115,7 +120,7 @@ bool tile_plan(int B, const ccnn_dims_t &d, TilePlan *out)
     if (want < 1) want = 1;
     if (want > 8) want = 8;
     for (int ms = want; ms >= 1; ms--) {
-        for (int nwv = tile_max_waves<T>(ms); nwv >= 4; nwv >>= 1) {
+        for (int nwv = tile_max_waves<T>(ms, forced_waves); nwv >= 4; nwv >>= 1) {
             if (ms > nwv) continue;
             for (int nch = 1; nch <= 8; nch <<= 1) {
                 const TileLayout L = tile_layout<T>(d.re, d.mre, nwv, ms, nch);
@@ -131,6 +136,14 @@ bool tile_plan(int B, const ccnn_dims_t &d, TilePlan *out)
         }
     }
     return false;
+}
+template bool tile_plan_waves<float>(int, const ccnn_dims_t &, int, TilePlan *);
+template bool tile_plan_waves<double>(int, const ccnn_dims_t &, int, TilePlan *);
+
+template <typename T>
+bool tile_plan(int B, const ccnn_dims_t &d, TilePlan *out)
+{
+    return tile_plan_waves<T>(B, d, tile_waves_env(), out);
 }
 template bool tile_plan<float>(int, const ccnn_dims_t &, TilePlan *);
 template bool tile_plan<double>(int, const ccnn_dims_t &, TilePlan *);

@@ -26,6 +26,11 @@ struct TilePlan {
 // Depends on B, the geometry and T only, never on the device, so workspace sizes can be computed anywhere.
 template <typename T>
 bool tile_plan(int B, const ccnn_dims_t &d, TilePlan *out);
+// The same with the wave count of full fp32 tiles given by the caller (8 | 16, else the default)
+// instead of read from CCNN_TILE_WAVES; tile_waves_env() reads that variable.
+template <typename T>
+bool tile_plan_waves(int B, const ccnn_dims_t &d, int forced_waves, TilePlan *out);
+int tile_waves_env();
 template <typename T, bool FLIP>
 int tile_train(const T *params, const T *cubes, const int *onehot, long first, int B, const ccnn_dims_t &d,
                const TilePlan &plan, T *pool, T *a1, T *d1, T *d2, T *probs, double *loss_values, T *part,

@@ -48,8 +48,9 @@ _WS_BYTES = {}
 
 def _mbgd_ws_bytes(lib, B, z, es):
     """ccnn_mbgd_workspace_bytes, remembered (the training loop asks on every step).  The size depends
-    on which implementation of the step the library picks, and CCNN_MBGD_PATH can override that."""
-    k = (B, z, es, os.environ.get("CCNN_MBGD_PATH"))
+    on which implementation of the step the library picks, and CCNN_MBGD_PATH / CCNN_TILE_WAVES can
+    override that."""
+    k = (B, z, es, os.environ.get("CCNN_MBGD_PATH"), os.environ.get("CCNN_TILE_WAVES"))
     n = _WS_BYTES.get(k)
     if n is None:
         n = _WS_BYTES[k] = lib.ccnn_mbgd_workspace_bytes(B, z, es)

@@ -335,8 +335,8 @@ int ccnn_comm_shares_device(ccnn_comm_t *comm, int *shared);
  * sums to every rank (one hop, world-1 vectors per rank over the links); via_owner = 1, they meet
  * at one owner rank per workgroup, which adds them and sends the total round (two hops,
  * 2 (world-1)/world of a vector per rank).  The sums are added in rank order either way: the
- * results are bit-identical.  Default: 1 from four ranks up (CCNN_COMM_EXCHANGE=direct|owner
- * overrides at creation).  Every rank must use the same setting for the same call.  No
+ * results are bit-identical.  Default: 0 (the owner form has not been timed over xGMI yet;
+ * CCNN_COMM_EXCHANGE=direct|owner overrides at creation).  Every rank must use the same setting for the same call.  No
  * counterpart in the reference. */
 int ccnn_comm_set_exchange(ccnn_comm_t *comm, int via_owner);
 /* Tear-down is two-phase across ranks: every rank first unmaps its peers' buffers

@@ -87,3 +87,21 @@ def test_tile_plans_fit_the_lds_for_every_geometry():
                 assert p.nwv in (4, 8, 16) and 1 <= p.ms <= min(p.nwv, 8) and p.nch in (1, 2, 4, 8)
                 assert p.tiles == (B + p.ms - 1) // p.ms
     assert fits > 3000
+
+
+def test_integration_sketch_compiles_against_the_header(tmp_path):
+    """Every ```cpp block of INTEGRATION.md that includes <ccnn.h> is compiled (-fsyntax-only) against
+    include/ccnn.h: the document a maintainer copies from cannot drift from the boundary it describes."""
+    import shutil
+    import subprocess
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = [b for b in re.findall(r"```cpp\n(.*?)```", text, flags=re.S) if "#include <ccnn.h>" in b]
+    assert blocks, "INTEGRATION.md lost its compilable sketch"
+    cxx = shutil.which("g++") or "g++"     # host code only: the sketch is what a plain C++ trainer would hold
+    for i, b in enumerate(blocks):
+        src = tmp_path / f"sketch{i}.cpp"
+        src.write_text(b)
+        r = subprocess.run([cxx, "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__",
+                            "-I", "/opt/rocm/include", "-I", os.path.join(ROOT, "include"), str(src)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr

@@ -4,6 +4,9 @@ with the bars per parameter group (tests/parity.py).
   config 2  KSC shape 512x614x176, fp64: gather, one SGD epoch, inference after it
   config 3  Indian-Pines shape 145x145x200, fp32 MBGD B = 128: every step of an epoch
   config 4  Pavia-U shape 610x340x103, fp32 MBGD B = 128 (one GPU): every step of an epoch
+  (KSC)     fp64 MBGD B = 100, the reference's canonical trainer: every step of an epoch
+  config 5  2048x2048x224 fp32, every pixel labelled: scene-fed forward over all pixels, gathers
+            whose output passes 2^31 elements, two steps of 2048 samples
 
 fp32: each GPU step starts from the oracle's weights, so a step's error is its own; a second
 replica runs free for the accuracy / argmax comparison at the end of the epoch."""
@@ -93,6 +96,174 @@ def test_config34_fp32_mbgd_b128_every_step_of_an_epoch(name, seed, counts, mbgd
         flipped_steps += nflip > 0
     print(f"{name}: {T // B} steps, {flipped_steps} of them decided by the near-tie rule")
     assert flipped_steps <= 3, f"{flipped_steps} steps needed the near-tie rule: that is not rounding any more"
-    # the free-running replica: one epoch of accumulated rounding, same predictions
-    assert parity.relerr(p_free.cpu().numpy(), p_ref) <= 1e-3
+    # The free-running replica: one epoch of accumulated rounding, same predictions.  The bar is
+    # derived, not chosen: every step above is within 1e-5 (per group) of the oracle's step from the
+    # same weights, and such differences add up at most linearly while the update map does not expand
+    # them (true at this step size: the observed drift, printed here, stays well below the sum), so
+    # after n steps the replicas differ by at most n x 1e-5 - and never more than 1e-3.
+    drift = parity.relerr(p_free.cpu().numpy(), p_ref)
+    bar = min(1e-3, (T // B) * 1e-5)
+    print(f"{name}: free-running replica differs from the oracle by {drift:.2e} after {T // B} steps (bar {bar:.1e})")
+    assert drift <= bar
     assert_predictions(p_free, g_test, p_ref, ref_test, tl, z, 1e-5)
+
+
+def test_ksc_fp64_mbgd_b100_every_step_of_an_epoch(mbgd_path):
+    """The reference's canonical trainer (gcn_mbgd_fp64.cu:931-1060: B = 100, lr = 0.5, mean over the
+    batch) on the KSC shape: every one of the epoch's 41 steps, started from the oracle's weights, to
+    1e-12 per parameter group and the per-sample losses to 1e-12, on each implementation of the step;
+    a replica that runs free through the epoch stays within 1e-9 (41 steps of 1e-12-sized differences
+    through a contraction that is not expansive at this step size) and predicts like the oracle."""
+    z, onehot, tl, ref_train, ref_test, g_train, g_test = prepared("ksc", 20242, 7, np.float64)
+    d = orc.dims(z)
+    T, B, lr = len(onehot), 100, 0.5
+    assert T // B == 41
+    oh_d = dev(onehot)
+    orc.srand(7)
+    p_ref = orc.init_params_f64(z, d.pout * B)
+    p_free = dev(p_ref)
+    lv = torch.zeros(B, dtype=torch.float64, device="cuda")
+    ws = ops.Workspace()
+    worst = {}
+    for i in range(T // B):
+        p_step = dev(p_ref)
+        ops.mbgd_step(p_step, g_train, oh_d, i * B, B, z, lr, loss_values=lv, workspace=ws)
+        ops.mbgd_step(p_free, g_train, oh_d, i * B, B, z, lr, workspace=ws)
+        lv_ref, _, _ = orc.mbgd_step(p_ref, ref_train, onehot, i * B, B, z, lr, want_grad=False)
+        assert parity.relerr(lv.cpu().numpy(), lv_ref) <= 1e-12, f"step {i}: loss"
+        errs = parity.assert_groups(p_step.cpu().numpy(), p_ref, d, 1e-12, f"fp64 MBGD step {i} ({mbgd_path})")
+        for k, e in errs.items():
+            worst[k] = max(worst.get(k, 0.0), e)
+    print(f"fp64 MBGD KSC B=100 ({mbgd_path}): worst per-group error over 41 steps {worst}")
+    assert parity.relerr(p_free.cpu().numpy(), p_ref) <= 1e-9
+    assert_predictions(p_free, g_test, p_ref, ref_test, tl, z, 1e-12)
+
+
+# ---------------------------------------------------------------------------------------------
+# config 5: AVIRIS-scale scene, 2048 x 2048 x 224, fp32, every pixel labelled.  The scene is drawn on
+# the device (3.8 GB); the host copy serves the oracle.  The reference's gather indexes its output
+# with int (gcn_sgd_fp64.cu:470-486: id*9*z overflows past 1 065 220 samples at 224 bands) and
+# preprocess048.cu:229-232 loops over 65 536-sample launches: here one call gathers 1.23 M samples.
+
+AV_X, AV_Y, AV_Z, _ = synth.SCENES["aviris"]
+
+
+@pytest.fixture(scope="module")
+def aviris():
+    from gcn_amd import prep
+    g = torch.Generator(device="cuda").manual_seed(20245)
+    scene_d = torch.rand(AV_X * AV_Y * AV_Z, generator=g, device="cuda", dtype=torch.float32)
+    labels = synth.make_labels(AV_X, AV_Y, None, None)                 # every pixel labelled, 13 classes
+    di = prep.scan_labels(labels, AV_X, AV_Y)
+    assert len(di) == AV_X * AV_Y
+    tr9, te9, onehot, tl = prep.build_index(labels, di, AV_X, AV_Y)
+    assert (len(tr9), len(te9)) == (3355443, 838861)
+    return {"scene_d": scene_d, "labels": labels, "tr9": tr9, "te9": te9, "onehot": onehot, "tl": tl}
+
+
+def cubes_by_indexing(scene_d, idx9_d, z, xy):
+    """out[i, b*9 + j] = scene[idx9[i, j] + b*x*y] with plain tensor indexing (the gather's definition)."""
+    off = (torch.arange(z, device=scene_d.device, dtype=torch.int64) * xy).view(1, z, 1)
+    return scene_d[idx9_d.to(torch.int64).view(-1, 1, 9) + off].view(idx9_d.shape[0], 9 * z)
+
+
+def test_config5_scene_forward_every_pixel(aviris):
+    """ccnn_forward_scene_f32 over all 4 194 304 pixels: equal, bit for bit, to gather + forward on
+    200 k pixels that include every border pixel (all four corners and edges: mirrored neighbours),
+    and to the oracle (1e-5, argmax wherever the top-2 margin is clear) on 2 048 of them."""
+    x, y, z = AV_X, AV_Y, AV_Z
+    sc = aviris["scene_d"]
+    rng = np.random.default_rng(5)
+    orc.srand(5)
+    params = orc.init_params_f32(z)
+    p_d = dev(params)
+    all9 = np.concatenate([aviris["tr9"], aviris["te9"]])
+    assert len(all9) == x * y
+    all9_d = dev(all9)
+    ws = ops.Workspace()
+    probs, am = ops.forward_scene(p_d, sc, all9_d, x, y, z, workspace=ws)
+    centre = all9[:, 4]
+    r, c = centre % x, centre // x
+    border = np.flatnonzero((r == 0) | (r == x - 1) | (c == 0) | (c == y - 1))
+    assert len(border) == 2 * x + 2 * y - 4
+    corners = {0, x - 1, (y - 1) * x, x * y - 1}
+    assert corners <= set(centre[border].tolist())
+    rest = np.setdiff1d(rng.choice(x * y, 200000, replace=False), border)
+    pick = np.concatenate([border, rest])[:200000 + len(border)]
+    assert len(pick) >= 200000
+    pick_d = torch.from_numpy(pick).cuda()
+    cubes = ops.gather(sc, all9_d[pick_d].contiguous(), x, y, z)
+    pr2, am2 = ops.forward(p_d, cubes, z, workspace=ws)
+    assert torch.equal(pr2, probs[pick_d]), "scene-fed forward differs from gather + forward"
+    assert torch.equal(am2, am[pick_d])
+    # the oracle on the border's corners + edges sample and on interior pixels
+    sub = np.concatenate([border[rng.choice(len(border), 1024, replace=False)], rest[:1024]])
+    sub_d = torch.from_numpy(sub).cuda()
+    cubes_h = cubes_by_indexing(sc, all9_d[sub_d].contiguous(), z, x * y).cpu().numpy()
+    scene_h = sc.cpu().numpy()
+    assert orc.gather(scene_h, all9[sub], x, y, z).tobytes() == cubes_h.tobytes(), "oracle gather differs from indexing"
+    del scene_h
+    pr_ref, am_ref = orc.forward(params, cubes_h, z)
+    pr = probs[sub_d].cpu().numpy()
+    assert parity.relerr(pr, pr_ref) <= 1e-5
+    top2 = np.sort(pr_ref.astype(np.float64), axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 100 * 1e-5 * top2[:, 1]
+    assert np.array_equal(am[sub_d].cpu().numpy()[clear], am_ref[clear])
+
+
+@pytest.mark.parametrize("how", ["planned", "one_shot"])
+def test_config5_gather_past_two_to_the_31_elements(aviris, how):
+    """1 228 800 fully labelled pixels (600 whole columns of the scene, borders included, in shuffled
+    order) x 2016 values = 2.48 G output elements: the dense plan (tiles staged in LDS) and the
+    one-shot call (ordered list) against tensor indexing, bit for bit, in 64 k-sample pieces."""
+    x, y, z = AV_X, AV_Y, AV_Z
+    sc = aviris["scene_d"]
+    all9 = np.concatenate([aviris["tr9"], aviris["te9"]])
+    cols = all9[:, 4] // x
+    block = all9[cols < 600]
+    n = len(block)
+    assert n == 600 * x and n * 9 * z > 2 ** 31
+    block = block[np.random.default_rng(6).permutation(n)]
+    idx_d = dev(block)
+    out = torch.empty((n, 9 * z), dtype=torch.float32, device="cuda")
+    out.fill_(-1.0)
+    if how == "planned":
+        plan = ops.GatherPlan(idx_d, x, y)
+        assert plan.dense, "a fully labelled block must take the tile kernel"
+        plan.gather(sc, z, out=out)
+    else:
+        ops.gather(sc, idx_d, x, y, z, out=out)
+    torch.cuda.synchronize()
+    step = 65536
+    for lo in range(0, n, step):
+        want = cubes_by_indexing(sc, idx_d[lo:lo + step], z, x * y)
+        assert torch.equal(out[lo:lo + step], want), f"samples [{lo}, {lo + step}) differ"
+
+
+def test_config5_two_fp32_steps_of_2048_past_two_to_the_31(aviris):
+    """Two fp32 MBGD steps of B = 2048 on cubes that sit BEYOND element 2^31 of a 1.23 M-sample cube
+    array (first = 1 100 000: the step's own 64-bit offsets), against the oracle per parameter
+    group with the near-tie rule of tests/parity.py."""
+    x, y, z, B = AV_X, AV_Y, AV_Z, 2048
+    sc = aviris["scene_d"]
+    tr9, onehot = aviris["tr9"], aviris["onehot"]
+    n = 1228800
+    first = 1100000
+    assert first * 9 * z > 2 ** 31 and first + 2 * B <= n
+    rng = np.random.default_rng(7)
+    sel = rng.permutation(len(tr9))[:n]
+    idx_d = dev(tr9[sel])
+    oh = np.ascontiguousarray(onehot[sel])
+    cubes = ops.gather(sc, idx_d, x, y, z)
+    oh_d = dev(oh)
+    cubes_h = cubes[first:first + 2 * B].cpu().numpy()
+    oh_h = np.ascontiguousarray(oh[first:first + 2 * B])
+    orc.srand(11)
+    p_ref = orc.init_params_f32(z)
+    lr = np.float32(0.04 * 128 / B)
+    lv = torch.zeros(B, dtype=torch.float64, device="cuda")
+    ws = ops.Workspace()
+    for i in range(2):
+        p_step = dev(p_ref)
+        ops.mbgd_step(p_step, cubes, oh_d, first + i * B, B, z, float(lr), loss_values=lv, workspace=ws)
+        p_ref, _ = parity.check_fp32_step(p_ref, p_step.cpu().numpy(), lv.cpu().numpy(), cubes_h, oh_h, i * B, B, z, lr)

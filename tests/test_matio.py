@@ -126,3 +126,16 @@ def test_reader_rejects_out_of_range_dimensions(tmp_path):
     for flag in (f"--mat-info={q}", f"--mat-stream={q}:DataSet"):
         r = subprocess.run([GCN, flag], capture_output=True, text=True, timeout=60)
         assert r.returncode != 0 and "dimensions" in r.stderr, (flag, r.stderr)
+
+
+def test_streaming_reader_rejects_bad_chunk_counts(tmp_path):
+    """CHUNK of --mat-stream: zero, negative or non-numeric is a usage error (not an endless loop or an
+    allocation of 2^64 values); a count beyond the variable is clamped to it."""
+    p = str(tmp_path / "c.mat")
+    a = np.arange(24, dtype=np.float64).reshape(4, 3, 2)
+    sio.savemat(p, {"DataSet": a})
+    for bad in ("0", "-5", "abc", "7x"):
+        r = subprocess.run([GCN, f"--mat-stream={p}:DataSet:{bad}"], capture_output=True, text=True, timeout=20)
+        assert r.returncode == 1 and "CHUNK" in r.stderr, (bad, r.stderr)
+    cls, dims, total, rss_kb = stream(p, "DataSet", 10 ** 15)
+    assert dims == (4, 3, 2) and total == a.sum() and rss_kb < 200 * 1024
