@@ -12,6 +12,10 @@
 // every device's memory (never whole in host memory); each device gathers its own slice of the
 // training cubes from its own copy of the scene on a side stream, and the test cubes are
 // gathered there while training already runs.
+// The multi-GPU form drives every device from a host thread of its own (the reference walks its
+// devices round-robin from one thread, hyper_version_mGPU_MBGD.cu:980-1091: at ten microseconds of
+// launch work per step and device, eight devices would wait for the host); the threads meet once
+// per epoch, for the loss.
 // Options (all before the positional arguments):
 //   --variant=V  --seed=N (default: time, like the reference)  --epochs=N (300)
 //   --batch=N (100)  --model=PATH (load weights instead of initialising)
@@ -29,11 +33,15 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <unistd.h>
@@ -186,6 +194,76 @@ Samples build_samples(const std::vector<double> &labels, int x, int y, int class
     return s;
 }
 
+// One host thread per device.  run(f) calls f(k) on worker k for every device at once and returns
+// when all are done; worker k makes device k current once and issues every HIP / RCCL call for it,
+// so no thread ever switches devices.  With a single device there are no workers: f(0) runs on the
+// caller's thread.  An error inside f ends the process through CK (error_util.h's convention).
+class Crew {
+public:
+    explicit Crew(const std::vector<int> &device_ids) : n_((int)device_ids.size())
+    {
+        if (n_ == 1) {
+            CK(hipSetDevice(device_ids[0]));
+            return;
+        }
+        for (int k = 0; k < n_; k++)
+            workers_.emplace_back([this, k, id = device_ids[k]] {
+                CK(hipSetDevice(id));
+                long seen = 0;
+                for (;;) {
+                    std::function<void(int)> job;
+                    {
+                        std::unique_lock<std::mutex> lk(mu_);
+                        go_.wait(lk, [&] { return quit_ || gen_ != seen; });
+                        if (quit_) return;
+                        seen = gen_;
+                        job = job_;
+                    }
+                    job(k);
+                    {
+                        std::lock_guard<std::mutex> lk(mu_);
+                        if (--pending_ == 0) done_.notify_one();
+                    }
+                }
+            });
+    }
+    ~Crew()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            quit_ = true;
+        }
+        go_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    Crew(const Crew &) = delete;
+    Crew &operator=(const Crew &) = delete;
+    int size() const { return n_; }
+    void run(const std::function<void(int)> &f)
+    {
+        if (n_ == 1) {
+            f(0);
+            return;
+        }
+        std::unique_lock<std::mutex> lk(mu_);
+        job_ = f;
+        pending_ = n_;
+        gen_++;
+        go_.notify_all();
+        done_.wait(lk, [&] { return pending_ == 0; });
+    }
+
+private:
+    int n_;
+    std::vector<std::thread> workers_;
+    std::mutex mu_;
+    std::condition_variable go_, done_;
+    std::function<void(int)> job_;
+    long gen_ = 0;
+    int pending_ = 0;
+    bool quit_ = false;
+};
+
 // Everything one device holds.
 template <typename T>
 struct Device {
@@ -269,12 +347,13 @@ struct Api<double> {
 
 // DataSet from the file into every device's scene buffer: the values are read (inflated,
 // converted to T) a chunk at a time into one of two pinned host buffers while the other one's
-// copies are still in flight on the devices' side streams.  Host memory: the two buffers.
+// copies are still in flight on the devices' side streams (each device's copies are issued by its
+// own thread of the crew).  Host memory: the two buffers.
 template <typename T>
-void stream_scene(matio::Stream &ds, const std::vector<int> &ids, const std::vector<T *> &scene,
-                  const std::vector<hipStream_t> &side)
+void stream_scene(matio::Stream &ds, Crew &crew, const std::vector<T *> &scene, const std::vector<hipStream_t> &side)
 {
     const size_t total = ds.numel();
+    const size_t nd = scene.size();
     size_t chunk = (size_t)(64u << 20) / sizeof(T);
     if (const char *e = getenv("CCNN_SCENE_CHUNK"))   // elements per chunk (tests cross chunk boundaries with a small value)
         if (atol(e) > 0) chunk = (size_t)atol(e);
@@ -282,13 +361,12 @@ void stream_scene(matio::Stream &ds, const std::vector<int> &ids, const std::vec
     T *buf[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> ev[2];
     for (int b = 0; b < 2; b++) {
-        CK(hipHostMalloc(reinterpret_cast<void **>(&buf[b]), chunk * sizeof(T), hipHostMallocDefault));
-        ev[b].resize(ids.size());
-        for (size_t k = 0; k < ids.size(); k++) {
-            CK(hipSetDevice(ids[k]));
-            CK(hipEventCreateWithFlags(&ev[b][k], hipEventDisableTiming));
-        }
+        CK(hipHostMalloc(reinterpret_cast<void **>(&buf[b]), chunk * sizeof(T), hipHostMallocPortable));
+        ev[b].resize(nd);
     }
+    crew.run([&](int k) {
+        for (int b = 0; b < 2; b++) CK(hipEventCreateWithFlags(&ev[b][k], hipEventDisableTiming));
+    });
     std::string err;
     size_t off = 0;
     for (int i = 0; off < total; i++) {
@@ -300,21 +378,19 @@ void stream_scene(matio::Stream &ds, const std::vector<int> &ids, const std::vec
             fprintf(stderr, "%s\n", err.c_str());
             exit(EXIT_FAILURE);
         }
-        for (size_t k = 0; k < ids.size(); k++) {
-            CK(hipSetDevice(ids[k]));
+        crew.run([&](int k) {
             CK(hipMemcpyAsync(scene[k] + off, buf[b], n * sizeof(T), hipMemcpyHostToDevice, side[k]));
             CK(hipEventRecord(ev[b][k], side[k]));
-        }
+        });
         off += n;
     }
-    for (int b = 0; b < 2; b++) {
-        for (size_t k = 0; k < ids.size(); k++) {
-            CK(hipSetDevice(ids[k]));
+    crew.run([&](int k) {
+        for (int b = 0; b < 2; b++) {
             CK(hipEventSynchronize(ev[b][k]));
             CK(hipEventDestroy(ev[b][k]));
         }
-        CK(hipHostFree(buf[b]));
-    }
+    });
+    for (int b = 0; b < 2; b++) CK(hipHostFree(buf[b]));
 }
 
 template <typename T>
@@ -354,14 +430,15 @@ double run(const Options &opt, const Variant &v, matio::Stream &ds, const std::v
 
     // Every device takes its own copy of the scene and gathers its own slice on its side stream
     // (the reference gathers everything on the master and hands slices out through host memory,
-    // hyper_version_mGPU_MBGD.cu:856-857, 923-952: same cubes, no device-to-device copies).
+    // hyper_version_mGPU_MBGD.cu:856-857, 923-952: same cubes, no device-to-device copies) - and
+    // every device has a host thread of its own for all of it.
+    Crew crew(devices);
     std::vector<Device<T>> dev(nd);
     std::vector<T *> scene_ptrs(nd);
     std::vector<hipStream_t> sides(nd);
-    for (int k = 0; k < nd; k++) {
+    crew.run([&](int k) {
         Device<T> &D = dev[k];
         D.id = devices[k];
-        CK(hipSetDevice(D.id));
         CK(hipStreamCreate(&D.st));
         CK(hipStreamCreate(&D.side));
         CK(hipEventCreateWithFlags(&D.train_ready, hipEventDisableTiming));
@@ -374,8 +451,8 @@ double run(const Options &opt, const Variant &v, matio::Stream &ds, const std::v
         if (D.gws_bytes) CK(hipMalloc(&D.gws, D.gws_bytes));
         scene_ptrs[k] = D.scene;
         sides[k] = D.side;
-    }
-    stream_scene<T>(ds, devices, scene_ptrs, sides);
+    });
+    stream_scene<T>(ds, crew, scene_ptrs, sides);
     ds.close();
     // test cubes: on the first device's side stream, behind its training gather - they are not
     // needed before the test loop, so the training steps below start without waiting for them
@@ -384,27 +461,22 @@ double run(const Options &opt, const Variant &v, matio::Stream &ds, const std::v
     T *test_d = dmalloc<T>((size_t)s.n_test * d.cube);
     hipEvent_t test_ready;
     CK(hipEventCreateWithFlags(&test_ready, hipEventDisableTiming));
-    for (int k = 0; k < nd; k++) {
-        Device<T> &D = dev[k];
-        CK(hipSetDevice(D.id));
-        CK(Api<T>::gather(D.scene, D.idx, slice, x, y, z, D.cubes, D.gws, D.gws_bytes, D.side));
-        CK(hipEventRecord(D.train_ready, D.side));
-        CK(hipStreamWaitEvent(D.st, D.train_ready, 0));
-    }
-    // the test gather is issued when the first training step has been queued (below): it then runs on
-    // the side stream beside the training kernels instead of in front of them
+    // the test gather is issued when the first training step has been queued (below, by the first
+    // device's thread): it then runs on the side stream beside the training kernels instead of in
+    // front of them
     auto gather_test_cubes = [&]() {
-        CK(hipSetDevice(dev[0].id));
         // the test list is already in pixel order: no ordering pass needed
         CK(Api<T>::gather(dev[0].scene, te_idx_d, s.n_test, x, y, z, test_d, nullptr, 0, dev[0].side));
         CK(hipEventRecord(test_ready, dev[0].side));
     };
     bool test_gather_issued = false;
 
-    // per-device training state, set up while the gathers run
-    for (int k = 0; k < nd; k++) {
+    // per device: the gather of its slice, then - while that runs - its training state
+    crew.run([&](int k) {
         Device<T> &D = dev[k];
-        CK(hipSetDevice(D.id));
+        CK(Api<T>::gather(D.scene, D.idx, slice, x, y, z, D.cubes, D.gws, D.gws_bytes, D.side));
+        CK(hipEventRecord(D.train_ready, D.side));
+        CK(hipStreamWaitEvent(D.st, D.train_ready, 0));
         std::vector<int> oh(s.onehot.begin() + (size_t)k * slice * classes,
                             s.onehot.begin() + (size_t)(k + 1) * slice * classes);
         D.onehot = to_device(oh);
@@ -415,7 +487,7 @@ double run(const Options &opt, const Variant &v, matio::Stream &ds, const std::v
                            : std::max(ccnn_mbgd_workspace_bytes(std::max(sub_b, 1), zg, (int)sizeof(T)),
                                       tail ? ccnn_mbgd_workspace_bytes(tail, zg, (int)sizeof(T)) : (size_t)0);
         CK(hipMalloc(&D.ws, D.ws_bytes ? D.ws_bytes : 1));
-    }
+    });
     // Multi-GPU gradient exchange: RCCL all-reduce + update, or (--exchange=oneshot) the library's
     // one-kernel exchange over directly mapped peer buffers, fused with the update.
     const bool oneshot = multi && !v.sgd && opt.exchange == "oneshot";
@@ -444,7 +516,7 @@ double run(const Options &opt, const Variant &v, matio::Stream &ds, const std::v
         close(saved_stdout);
         NCK(init_rc);
     }
-    for (int k = 0; k < nd; k++) CK(hipEventSynchronize(dev[k].train_ready));
+    crew.run([&](int k) { CK(hipEventSynchronize(dev[k].train_ready)); });
     fprintf(stdout,
             "[Samples prepared with %d Nearest-Neighbor-Pixels Strategy] Proportion of Training Samples: %d%%  Execution "
             "time: %.3f sec\n",
@@ -464,7 +536,9 @@ double run(const Options &opt, const Variant &v, matio::Stream &ds, const std::v
         ccnn_lr_sched_t sched;
         CK(ccnn_host_sched_init(&sched, v.fifo, v.f32));
         fprintf(stdout, "%s] lr = %lf\n", head, lr);
-        std::vector<double> loss_h((size_t)std::max<long>(batch_num + 1, 1) * std::max(sub_b, 1));
+        const size_t loss_n = (size_t)std::max<long>(batch_num + 1, 1) * std::max(sub_b, 1);
+        std::vector<std::vector<double>> loss_h(nd, std::vector<double>(loss_n));
+        std::vector<int> xch_status(nd, 0);
         for (int iter = 0; iter < opt.epochs; iter++) {
             Clock::time_point t_it = Clock::now();
             double single_rate = 0;
@@ -483,75 +557,62 @@ double run(const Options &opt, const Variant &v, matio::Stream &ds, const std::v
                 if (iter < 300) logloss[iter] = single_rate;
                 if (single_rate < v.min_err) break;   // before printing and scheduling (gcn_sgd_fp64.cu:860-861)
             } else {
-                for (long i0 = 0; i0 < batch_num; i0++) {
-                    for (int k = 0; k < nd; k++) {
-                        Device<T> &D = dev[k];
-                        if (nd > 1) CK(hipSetDevice(D.id));
+                // One epoch of device k, on its own thread: every step is queued without waiting for
+                // anything (the kernels of a step wait for their peers on the devices; RCCL orders its
+                // all-reduce on the device's stream), then the epoch's per-sample losses come back in
+                // one copy.  The devices' steps are therefore enqueued side by side, not one device
+                // after another (hyper_version_mGPU_MBGD.cu:980-1091 walks them in turn).
+                crew.run([&](int k) {
+                    Device<T> &D = dev[k];
+                    for (long i0 = 0; i0 < batch_num; i0++) {
                         double *lv = D.loss + i0 * sub_b;
                         if (!exchange) {
                             CK(Api<T>::step(D.params, D.cubes, D.onehot, i0 * sub_b, sub_b, zg, lr, lv, D.ws, D.ws_bytes, D.st));
                         } else if (oneshot) {
-                            // gradient, exchange with the other devices and update in two launches; the
-                            // launches are asynchronous, so device k's kernel waits for its peers' while
-                            // this loop goes on to start them
+                            // gradient, exchange with the other devices and update in two launches
                             CK(Api<T>::step_dp(xch[k], D.params, D.cubes, D.onehot, i0 * sub_b, sub_b, zg, lr, B, lv, D.ws,
                                                D.ws_bytes, D.st));
                         } else {
+                            // gradient, all-reduce, update: replaces weight broadcast + slab gather + master
+                            // update (hyper_version_mGPU_MBGD.cu:962-978, 1093-1171)
                             CK(Api<T>::grad(D.params, D.cubes, D.onehot, i0 * sub_b, sub_b, zg, D.grad, lv, D.ws, D.ws_bytes,
                                             D.st));
+                            if (nd > 1) NCK(ncclAllReduce(D.grad, D.grad, d.nparams, Api<T>::nccl, ncclSum, comms[k], D.st));
+                            CK(Api<T>::update(D.params, D.grad, lr, zg, B, d.nparams, D.st));
+                        }
+                        if (k == 0 && !test_gather_issued) {   // the first step is queued: the test cubes are gathered beside the training
+                            gather_test_cubes();
+                            test_gather_issued = true;
                         }
                     }
-                    if (!test_gather_issued) {   // the first step is queued: the test cubes are gathered beside the training
-                        gather_test_cubes();
-                        test_gather_issued = true;
+                    if (k == 0 && tail) {
+                        double *lv = D.loss + batch_num * sub_b;
+                        CK(Api<T>::step(D.params, D.cubes, D.onehot, batch_num * sub_b, tail, zg, lr, lv, D.ws, D.ws_bytes, D.st));
                     }
-                    if (oneshot) {
-                        // nothing left to do: the step above exchanged and updated
-                    } else if (nd > 1) {
-                        // replaces weight broadcast + slab gather + master update
-                        // (hyper_version_mGPU_MBGD.cu:962-978, 1093-1171)
-                        NCK(ncclGroupStart());
-                        for (int k = 0; k < nd; k++)
-                            NCK(ncclAllReduce(dev[k].grad, dev[k].grad, d.nparams, Api<T>::nccl, ncclSum, comms[k], dev[k].st));
-                        NCK(ncclGroupEnd());
-                        for (int k = 0; k < nd; k++) {
-                            CK(hipSetDevice(dev[k].id));
-                            CK(Api<T>::update(dev[k].params, dev[k].grad, lr, zg, B, d.nparams, dev[k].st));
-                        }
-                    }
-                }
-                if (tail) {
-                    Device<T> &D = dev[0];
-                    double *lv = D.loss + batch_num * sub_b;
-                    CK(Api<T>::step(D.params, D.cubes, D.onehot, batch_num * sub_b, tail, zg, lr, lv, D.ws, D.ws_bytes, D.st));
-                }
-                // one D2H per device per epoch; host adds the per-sample losses in order
+                    // one D2H per device per epoch
+                    CK(hipMemcpyAsync(loss_h[k].data(), D.loss, sizeof(double) * (batch_num * sub_b + (k == 0 ? tail : 0)),
+                                      hipMemcpyDeviceToHost, D.st));
+                    CK(hipStreamSynchronize(D.st));
+                    // a wait that ran out inside the exchange leaves the parameters at the last completed
+                    // step and raises the status word
+                    if (oneshot) CK(ccnn_comm_status(xch[k], &xch_status[k]));
+                });
+                // the host adds the per-sample losses in device and sample order
                 float loss32 = 0;
                 double loss64 = 0;
                 for (int k = 0; k < nd; k++) {
-                    CK(hipSetDevice(dev[k].id));
-                    CK(hipMemcpyAsync(loss_h.data(), dev[k].loss, sizeof(double) * (batch_num * sub_b + tail),
-                                      hipMemcpyDeviceToHost, dev[k].st));
-                    CK(hipStreamSynchronize(dev[k].st));
-                    for (long j = 0; j < batch_num * sub_b + tail; j++) {
-                        if (v.f32) loss32 = loss32 + loss_h[j];   // `float loss` (gcn_mbgd_fp32.cu:882, 1027)
-                        else loss64 = loss64 + loss_h[j];
+                    for (long j = 0; j < batch_num * sub_b + (k == 0 ? tail : 0); j++) {
+                        if (v.f32) loss32 = loss32 + loss_h[k][j];   // `float loss` (gcn_mbgd_fp32.cu:882, 1027)
+                        else loss64 = loss64 + loss_h[k][j];
                     }
                 }
                 single_rate = (v.f32 ? (double)loss32 : loss64) / s.n_train;
                 if (iter < 300) logloss[iter] = single_rate;
-                if (oneshot) {
-                    // a wait that ran out inside the exchange leaves the parameters at the last completed
-                    // step and raises the status word: stop instead of training on
-                    for (int k = 0; k < nd; k++) {
-                        int st = 0;
-                        CK(hipSetDevice(dev[k].id));
-                        CK(ccnn_comm_status(xch[k], &st));
-                        if (st) {
-                            fprintf(stderr, "%s:%d: device %d gave up waiting for a peer inside the gradient exchange (epoch %d)\n",
-                                    __FILE__, __LINE__, dev[k].id, iter + 1);
-                            exit(EXIT_FAILURE);
-                        }
+                for (int k = 0; k < nd; k++) {
+                    if (xch_status[k]) {   // stop instead of training on
+                        fprintf(stderr, "%s:%d: device %d gave up waiting for a peer inside the gradient exchange (epoch %d)\n",
+                                __FILE__, __LINE__, dev[k].id, iter + 1);
+                        exit(EXIT_FAILURE);
                     }
                 }
             }
@@ -577,15 +638,13 @@ double run(const Options &opt, const Variant &v, matio::Stream &ds, const std::v
 
     // test on the first device
     Clock::time_point t_test = Clock::now();
-    if (!test_gather_issued) gather_test_cubes();   // inference only, or per-sample SGD
     CK(hipSetDevice(dev[0].id));
+    if (!test_gather_issued) gather_test_cubes();   // inference only, or per-sample SGD
     CK(hipEventSynchronize(test_ready));   // the test cubes were gathered on the side stream meanwhile
-    for (int k = 0; k < nd; k++) {          // nothing reads the scene copies any more
-        CK(hipSetDevice(dev[k].id));
+    crew.run([&](int k) {                   // nothing reads the scene copies any more
         CK(hipFree(dev[k].scene));
         dev[k].scene = nullptr;
-    }
-    CK(hipSetDevice(dev[0].id));
+    });
     int *argmax_d = dmalloc<int>(s.n_test), *count_d = dmalloc<int>(1), *tl_d = to_device(s.test_labels);
     const size_t fws_bytes = ccnn_forward_workspace_bytes(s.n_test, zg, (int)sizeof(T));
     void *fws = nullptr;
@@ -597,10 +656,7 @@ double run(const Options &opt, const Variant &v, matio::Stream &ds, const std::v
     CK(hipStreamSynchronize(dev[0].st));
     fprintf(stdout, "[Cube CNN testing] Execution time is %.3f sec. ", secs(t_test));
     if (oneshot) {
-        for (int k = 0; k < nd; k++) {
-            CK(hipSetDevice(dev[k].id));
-            CK(hipDeviceSynchronize());
-        }
+        crew.run([&](int) { CK(hipDeviceSynchronize()); });
         for (auto c : xch) ccnn_comm_disconnect(c);
         for (auto c : xch) ccnn_comm_destroy(c);
         CK(hipSetDevice(dev[0].id));
@@ -626,7 +682,8 @@ int preprocess_dump(matio::Stream &ds, const std::vector<double> &labels, int x,
     double *scene_d = dmalloc<double>((size_t)x * y * z);
     hipStream_t side;
     CK(hipStreamCreate(&side));
-    stream_scene<double>(ds, {device}, {scene_d}, {side});
+    Crew crew({device});
+    stream_scene<double>(ds, crew, {scene_d}, {side});
     ds.close();
     std::vector<double> train((size_t)s.n_train * d.cube), test((size_t)s.n_test * d.cube);
     struct Part {
@@ -821,9 +878,31 @@ int main(int argc, char *argv[])
         return 1;
     }
     std::vector<int> devices;
+    // Rehearsal hook for boxes with fewer GPUs than the run wants: CCNN_CLI_DEVICE_MAP=0,0 runs the
+    // device slots 0 and 1 of `gcn DATASET.mat 2 0` both on physical device 0 (own streams, own
+    // host threads, own parameter copies: the multi-device driver as it is, minus the second card;
+    // RCCL refuses two ranks on one GPU, so this needs --exchange=oneshot).
+    std::vector<int> device_map;
+    if (const char *m = getenv("CCNN_CLI_DEVICE_MAP")) {
+        for (const char *q = m; *q;) {
+            char *end = nullptr;
+            const long id = strtol(q, &end, 10);
+            if (end == q || id < 0 || id >= count) {
+                fprintf(stderr, "CCNN_CLI_DEVICE_MAP: '%s' is not a list of device ordinals below %d\n", m, count);
+                return 1;
+            }
+            device_map.push_back((int)id);
+            q = *end == ',' ? end + 1 : end;
+            if (*end && *end != ',') {
+                fprintf(stderr, "CCNN_CLI_DEVICE_MAP: '%s' is not a comma-separated list\n", m);
+                return 1;
+            }
+        }
+    }
+    const int slots = device_map.empty() ? count : (int)device_map.size();
     if (multi) {
         const int device_num = atoi(opt.pos[1].c_str()), master = atoi(opt.pos[2].c_str());
-        if (device_num <= 0 || device_num > count || master < 0 || master >= device_num) {
+        if (device_num <= 0 || device_num > slots || master < 0 || master >= device_num) {
             fprintf(stderr, "Device number error: %d device(s) available, asked for %d with master %d\n", count, device_num, master);
             return 1;
         }
@@ -839,6 +918,13 @@ int main(int argc, char *argv[])
         }
         devices.push_back(dv);
         fprintf(stdout, "[Cube CNN training with %s] Training implemented on Device %d.\n", algo, dv);
+    }
+    if (multi && !device_map.empty()) {
+        for (int &dv : devices) dv = device_map[dv];
+        if (opt.exchange != "oneshot" && devices.size() > 1) {
+            fprintf(stderr, "CCNN_CLI_DEVICE_MAP with several slots needs --exchange=oneshot (RCCL wants one GPU per rank)\n");
+            return 1;
+        }
     }
 
     // labels whole (x*y doubles); DataSet is only opened here and streamed to the devices later

@@ -146,6 +146,56 @@ def test_multi_gpu_form_fp32_with_one_device(tmp_path, extra):
     assert abs(float(acc_line.split(" ")[9].rstrip("%")) - 100 * acc_ref) <= 0.1 + 1e-9
 
 
+@pytest.mark.parametrize("variant,dtype,lr,fifo,ndev", [("mbgd_fp64", np.float64, 0.5, 1.0, 2), ("mbgd_fp32", np.float32, 0.04, 100.0, 2),
+                                                       ("mbgd_fp64", np.float64, 0.5, 1.0, 4)])
+def test_multi_gpu_form_with_several_device_slots(tmp_path, variant, dtype, lr, fifo, ndev):
+    """`gcn DATASET.mat n 0` with n device slots (CCNN_CLI_DEVICE_MAP puts them all on the one GPU
+    of the test box): one host thread per slot, every slot its own slice, streams and parameter
+    copy, the sums traded inside the step.  Against the oracle's replay of the reference's
+    master / worker step (hyper_version_mGPU_MBGD.cu:903-1171: slot k owns samples
+    [k T/n, (k+1) T/n) and takes B/n of them per step; mean over the global batch in fp64) - in fp32
+    against the same sub-batches pushed through the single-device trainer's plain-sum update."""
+    path, scene, labels = make_dataset(tmp_path, dtype)
+    B, epochs = 20, 2
+    out = run_gcn(tmp_path, [f"--variant={variant}", f"--seed={SEED}", f"--epochs={epochs}", f"--batch={B}",
+                             "--exchange=oneshot", path, str(ndev), "0"],
+                  env={"CCNN_CLI_DEVICE_MAP": ",".join(["0"] * ndev)})
+    d = orc.dims(Z)
+    di = orc.scan_labels(labels, X, Y)
+    tr9, te9, onehot, tl = orc.build_index(labels, di, X, Y)
+    orc.shuffle(tr9, onehot, SEED)
+    p = orc.init_params_f32(Z) if dtype == np.float32 else orc.init_params_f64(Z, d.pout * B)
+    sc = scene.astype(dtype)
+    train, test = orc.gather(sc, tr9, X, Y, Z), orc.gather(sc, te9, X, Y, Z)
+    T, sub_b, slice_len = len(onehot), B // ndev, len(onehot) // ndev
+    sched = orc.Sched(dtype, fifo)
+    cur = dtype(lr)
+    l_ref = []
+    for _ in range(epochs):
+        per_dev = [[] for _ in range(ndev)]
+        for i0 in range(T // B):
+            firsts = [orc.mgpu_first_sample(T, ndev, B, k, i0) for k in range(ndev)]
+            assert firsts == [k * slice_len + i0 * sub_b for k in range(ndev)]
+            # the step's B samples side by side: one oracle step over them is the summed update
+            rows = np.concatenate([np.arange(f, f + sub_b) for f in firsts])
+            lv, _, _ = orc.mbgd_step(p, np.ascontiguousarray(train[rows]), np.ascontiguousarray(onehot[rows]), 0,
+                                     len(rows), Z, cur, want_grad=False)
+            for k in range(ndev):
+                per_dev[k].extend(lv[k * sub_b:(k + 1) * sub_b])
+        tot = dtype(0) if dtype == np.float32 else 0.0
+        for k in range(ndev):                 # the host adds device after device, sample after sample
+            for v in per_dev[k]:
+                tot = dtype(np.float64(tot) + v) if dtype == np.float32 else tot + v
+        l_ref.append(float(tot) / T)
+        _, nl = sched.step(l_ref[-1], float(cur))
+        cur = dtype(nl)
+    _, am = orc.forward(p, test, Z)
+    losses, acc_line, _ = parse(out)
+    assert np.allclose(losses, l_ref, rtol=2e-5, atol=1e-6), (losses, l_ref)
+    assert abs(float(acc_line.split(" ")[9].rstrip("%")) - 100 * float(np.mean(am + 1 == tl))) <= 0.1 + 1e-9
+    assert f"Training implemented on {ndev} Device(s), master 0." in out
+
+
 def test_tail_batch_kept(tmp_path):
     """--tail=keep trains the last T % B samples as a short batch (hyper_version_MBGD.cu:780, 794-796)."""
     path, scene, labels = make_dataset(tmp_path, np.float64)
