@@ -508,21 +508,21 @@ struct UpdateRule {
     }
 };
 
-// Sum over rows b = rg, rg+8, ... of term(b), 16 loads in flight; then over the 8 row groups.
-template <typename T, typename Term>
+// Sum over rows b = rg, rg+8, ... of term(b), U loads in flight; then over the 8 row groups.
+template <typename T, int U = 16, typename Term>
 __device__ __forceinline__ T colsum8(int B, int rg, int c, T *red, Term term)
 {
     T acc = 0;
-    for (int b0 = rg; b0 < B; b0 += 8 * 16) {
-        T v[16];
+    for (int b0 = rg; b0 < B; b0 += 8 * U) {
+        T v[U];
 #pragma unroll
-        for (int u = 0; u < 16; u++) {
+        for (int u = 0; u < U; u++) {
             const int b = b0 + 8 * u;
             const T x = term(b < B ? b : (B > 0 ? B - 1 : 0));   // clamped load, masked value (B == 0: row 0 exists, unused)
             v[u] = b < B ? x : T(0);
         }
 #pragma unroll
-        for (int u = 0; u < 16; u++) acc = acc + v[u];
+        for (int u = 0; u < U; u++) acc = acc + v[u];
     }
     red[rg * 64 + c] = acc;
     __syncthreads();
@@ -844,9 +844,11 @@ template <typename T, int NBUF>
 __global__ __launch_bounds__(CB_THREADS) void conv_bwd_batch(const T *__restrict__ cubes, long first,
                                                              const T *__restrict__ dp, const T *__restrict__ pool,
                                                              const unsigned char *__restrict__ px, int B,
-                                                             int cube_elems, int re, int mre, T *__restrict__ part)
+                                                             int cube_elems, int re, int mre, T *__restrict__ part,
+                                                             unsigned *zero_ctr)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (zero_ctr && blockIdx.x == 0 && threadIdx.x < TRAIN_ZERO_INTS) zero_ctr[threadIdx.x] = 0;   // for the batch sums that follow
     const ConvBwdLds<T> L(re, mre);
     T *base = reinterpret_cast<T *>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1104,6 +1106,243 @@ __global__ __launch_bounds__(GB_THREADS) void grad_reduce_big(int B, int pout, i
     }
 }
 
+// Batch sums for the largest batches, the batch split over WORKGROUPS as well (grad_reduce_big gives a
+// 16 x 16 tile of dW1 all rows of the batch: every operand value is fetched from L2 once per tile,
+// 64 bytes of a row at a time - 49 MB of L2 traffic for 4 MB of data at 2048 samples, and the launch
+// is bound by those requests).  Here a workgroup takes one 16-feature tile of pool and ALL hundred
+// neurons for one slice of the batch:
+//   npt x nsl workgroups   p tile pt, rows [sl bs, (sl + 1) bs): its rows of d1 are one contiguous run
+//                          of memory and come in with 16-byte loads, all issued before anything else
+//                          (one memory round trip), then go through LDS a chunk of GS_CH rows at a
+//                          time (double-buffered); wave w multiplies neuron tile w.  Slice sl runs on
+//                          XCD sl mod 8, so a slice of d1 is fetched into one L2.  The [16 x 112]
+//                          partial goes to memory write-through; the workgroup that arrives LAST at
+//                          the p tile's counter adds the nsl partials in slice order (the same order
+//                          whoever arrives last: bit-identical results) and applies the update.
+//   then the column sums exactly as in grad_reduce_big (conv-gradient partials, dW2, db1, db2).
+// No workgroup ever waits for another.  Hand-over inside the launch: the partials are stored with
+// agent-scope write-through stores and every wave waits for their acknowledgement before the
+// workgroup arrives (what a release fence does, minus the write-back of an L2 that holds nothing else
+// of this kernel's); the last arriver reads them past its caches.  The counters must be zero at
+// launch: the kernel that precedes this one in the step clears them, and the last arriver leaves
+// them at zero again.
+#ifndef CCNN_SPLIT_PROBE
+#define CCNN_SPLIT_PROBE 0
+#endif
+// Diagnostic builds only (-DCCNN_SPLIT_TIMING): thread 0 of every dW1 workgroup stamps the 100 MHz wall
+// clock at GS_TICK(k); ccnn_debug_split_ticks() returns the stamps of the last launch ([workgroup][8]).
+#ifdef CCNN_SPLIT_TIMING
+__device__ unsigned long long g_split_ticks[1024 * 8];
+#define GS_TICK(k)                                                                             \
+    do {                                                                                       \
+        if (threadIdx.x == 0 && blockIdx.x < 1024) g_split_ticks[blockIdx.x * 8 + (k)] = wall_clock64(); \
+    } while (0)
+#else
+#define GS_TICK(k) do { } while (0)
+#endif
+constexpr int GS_THREADS = 512;
+constexpr int GS_LDN = 104;       // LDS row of d1: 100 neurons, 16-byte aligned rows
+constexpr int GS_NCHK = 4;        // chunks of a slice held in registers
+template <typename T>
+struct SplitCfg {
+    static constexpr int CH = sizeof(T) == 4 ? 64 : 32;          // rows per chunk
+    static constexpr int BS_MAX = CH * GS_NCHK;                  // rows per slice
+    static constexpr size_t smem = 2 * (size_t)CH * (GS_LDN + 16) * sizeof(T);
+    // slices: whole groups of eight (one per XCD), each at most BS_MAX rows
+    static int slices(int B) { return ((B + BS_MAX - 1) / BS_MAX + 7) & ~7; }
+    static int slice_rows(int B) { return ((B + slices(B) - 1) / slices(B) + 3) & ~3; }
+    static size_t partial_elems(int B, int pout) { return (size_t)((pout + 15) / 16) * slices(B) * 7 * 256; }
+};
+constexpr int GS_CTR_INTS = TRAIN_ZERO_INTS;  // one arrival counter per p tile (at most 134: 448 bands)
+
+#ifndef CCNN_GS_WPE
+#define CCNN_GS_WPE 4    // waves per SIMD the registers must leave room for: two workgroups per compute unit
+#endif
+#ifndef CCNN_GS_CU
+#define CCNN_GS_CU 8     // rows in flight per thread in the column sums
+#endif
+template <typename T, int NO>
+__global__ __launch_bounds__(GS_THREADS, CCNN_GS_WPE) void grad_reduce_split(int B, int pout, int off_w1, int off_b1, int off_w2,
+                                                                int off_b2, const T *__restrict__ pool,
+                                                                const T *__restrict__ a1, const T *__restrict__ d1,
+                                                                const T *__restrict__ d2, const T *__restrict__ slab,
+                                                                int slab_rows, int npt, int nsl, int bs, int nb_w0,
+                                                                int nb_w2, int nb_b1, T *part1, unsigned *ctr,
+                                                                T *__restrict__ grad, UpdateRule<T> upd)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename Vec16<T>::type V;
+    constexpr int VW = Vec16<T>::W;
+    constexpr int CH = SplitCfg<T>::CH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int no = NO ? NO : (off_b2 - off_w2) / H;
+    int blk = blockIdx.x;
+#if CCNN_SPLIT_PROBE == 1   // diagnostic builds: the dW1 workgroups alone / the column sums alone
+    if (blk >= npt * nsl) return;
+#elif CCNN_SPLIT_PROBE == 2
+    if (blk < npt * nsl) return;
+#endif
+    if (blk < npt * nsl) {
+        const int pt = blk / nsl, sl = blk - pt * nsl;   // nsl is a multiple of 8: slice sl runs on XCD sl mod 8
+        const int p0 = pt * 16;
+        GS_TICK(0);
+        const int b_lo = min(sl * bs, B), len = min(b_lo + bs, B) - b_lo;   // this slice's rows (none: a zero partial)
+        const int b_ld = min(b_lo, B - 1);                                  // (a valid row for the loads of an empty slice)
+        T *d1s = reinterpret_cast<T *>(smem);                  // [2][CH][GS_LDN]
+        T *pls = d1s + 2 * CH * GS_LDN;                        // [2][CH][16]
+        // ---- every load of the slice, before anything waits (clamped, unconditional) ----
+        constexpr int DV = CH * H / VW;                        // vectors of a d1 chunk (rows are contiguous in memory)
+        constexpr int DPT = (DV + GS_THREADS - 1) / GS_THREADS;
+        constexpr int PV = CH * 16 / VW;                       // vectors of a pool chunk
+        static_assert(PV <= GS_THREADS, "one pool vector per thread");
+        V dv[GS_NCHK][DPT], pv[GS_NCHK];
+        const V *d1v = reinterpret_cast<const V *>(d1 + (long)b_ld * H);
+        const long d1_last = (long)max(len, 1) * H / VW - 1;
+        const int pr = tid / (16 / VW), pc = tid % (16 / VW);   // pool chunk: row, vector of the row
+        const bool pcol_ok = p0 + pc * VW < pout;               // (pout is whole vectors)
+        const T *psrc = pool + (long)b_ld * pout + min(p0 + pc * VW, pout - VW);
+#pragma unroll
+        for (int c = 0; c < GS_NCHK; c++) {
+#pragma unroll
+            for (int u = 0; u < DPT; u++) dv[c][u] = d1v[min((long)c * DV + u * GS_THREADS + tid, d1_last)];
+            pv[c] = *reinterpret_cast<const V *>(psrc + (long)min(c * CH + pr, max(len, 1) - 1) * pout);
+        }
+        GS_TICK(1);
+        const int col = lane & 15, kq = lane >> 4;
+        const int n0 = wave * 16;
+        const bool nv = n0 + col < H;
+        typename Mma<T>::acc_t acc = {0, 0, 0, 0};
+        const int nchunks = (len + CH - 1) / CH;
+#pragma unroll
+        for (int c = 0; c < GS_NCHK; c++) {
+            if (c < nchunks) {
+                T *db = d1s + (c & 1) * CH * GS_LDN, *pb = pls + (c & 1) * CH * 16;
+#pragma unroll
+                for (int u = 0; u < DPT; u++) {
+                    const int e = u * GS_THREADS + tid;
+                    if (e < DV) {
+                        const int r = (e * VW) / H, cc = e * VW - r * H;
+                        V v = dv[c][u];
+                        if (c * CH + r >= len) v = V{};          // rows past the slice: zeros in the product
+                        *reinterpret_cast<V *>(db + r * GS_LDN + cc) = v;
+                    }
+                }
+                if (tid < PV) {
+                    V v = pv[c];
+                    if (c * CH + pr >= len || !pcol_ok) v = V{};
+                    *reinterpret_cast<V *>(pb + pr * 16 + pc * VW) = v;
+                }
+                // one barrier per chunk: whoever passes it has finished the products of chunk c - 1, so
+                // chunk c + 1 may overwrite that buffer
+                lds_barrier();
+                if (c == 0) GS_TICK(2);
+                if (wave < 7) {
+                    const T *ap = pb + kq * 16 + col, *bp = db + kq * GS_LDN + min(n0 + col, H - 1);
+#pragma unroll 8
+                    for (int k = 0; k < CH / 4; k++) {
+                        const T a = ap[4 * k * 16];
+                        const T b = bp[4 * k * GS_LDN];
+                        acc = Mma<T>::mma(a, nv ? b : T(0), acc);
+                    }
+                }
+            }
+        }
+        GS_TICK(3);
+        // ---- the slice's partial, written through; then arrive ----
+        T *mine = part1 + (((size_t)pt * nsl + sl) * 7 + (wave < 7 ? wave : 0)) * 256;
+        if (wave < 7) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) __hip_atomic_store(mine + r * 64 + lane, acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_s_waitcnt(0);   // this wave's stores are acknowledged
+        __shared__ unsigned last_flag;
+        __syncthreads();                  // ... and every wave's
+        GS_TICK(4);
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(ctr + pt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last_flag = old == (unsigned)nsl - 1;
+            if (old == (unsigned)nsl - 1) __hip_atomic_store(ctr + pt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        GS_TICK(5);
+        if (!last_flag || wave >= 7) return;
+        // ---- last to arrive: the nsl partials in slice order, past the caches ----
+        const T *src = part1 + ((size_t)pt * nsl * 7 + wave) * 256 + lane;
+        T tot[4] = {0, 0, 0, 0};
+        for (int s0 = 0; s0 < nsl; s0 += 8) {
+            T v[8][4];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    v[u][r] = __hip_atomic_load(src + (size_t)(s0 + u) * 7 * 256 + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) tot[r] = tot[r] + v[u][r];
+        }
+        GS_TICK(6);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int p = p0 + Mma<T>::row(lane, r), n = n0 + col;
+            if (p < pout && nv) upd.apply(grad, off_w1 + n + H * p, tot[r]);
+        }
+        GS_TICK(7);
+        return;
+    }
+    blk -= npt * nsl;
+    T *red = reinterpret_cast<T *>(smem);
+    if (blk < nb_w0) {
+        const int c = tid & 63, rg = tid >> 6;
+        const int k = min(blk * 64 + c, F * K + F - 1);
+        // (rows in flight per thread, measured at 2048 / 4096 samples: 4 -> 13.5 / 25.9 us for the launch,
+        // 8 -> 11.7 / 25.0, 16 -> 11.5 / 28.4, 32 -> 22.0 / 44.4: more is not better here)
+        const T tot = colsum8<T, CCNN_GS_CU>(slab_rows, rg, c, red, [&](int b) { return slab[(long)b * (F * K + F) + k]; });
+        if (rg == 0 && blk * 64 + c < F * K + F) upd.apply(grad, k, tot);   // partial layout = W0 | b0 = params[0..)
+        return;
+    }
+    blk -= nb_w0;
+    const int c = tid & 15, rg = tid >> 4;   // 16 columns x 32 row groups
+    auto colsum32 = [&](auto term) {
+        T acc = 0;
+        constexpr int CU = CCNN_GS_CU;   // rows in flight per thread
+        for (int b0 = rg; b0 < B; b0 += 32 * CU) {
+            T v[CU];
+#pragma unroll
+            for (int u = 0; u < CU; u++) {
+                const int b = b0 + 32 * u;
+                const T x = term(min(b, B - 1));   // clamped load, masked value
+                v[u] = b < B ? x : T(0);
+            }
+#pragma unroll
+            for (int u = 0; u < CU; u++) acc = acc + v[u];
+        }
+        red[rg * 16 + c] = acc;
+        __syncthreads();
+        T tot = 0;
+        if (rg == 0) {
+#pragma unroll
+            for (int r = 0; r < 32; r++) tot = tot + red[r * 16 + c];
+        }
+        return tot;
+    };
+    if (blk < nb_w2) {
+        const int k = min(blk * 16 + c, H * no - 1);   // k = o + classes * n
+        const int nn = k / no, o = k - nn * no;
+        const T tot = colsum32([&](int b) { return a1[(long)b * H + nn] * d2[(long)b * no + o]; });
+        if (rg == 0 && blk * 16 + c < H * no) upd.apply(grad, off_w2 + k, tot);
+    } else if (blk < nb_w2 + nb_b1) {
+        const int q = blk - nb_w2;
+        const int n = min(q * 16 + c, H - 1);
+        const T tot = colsum32([&](int b) { return d1[(long)b * H + n]; });
+        if (rg == 0 && q * 16 + c < H) upd.apply(grad, off_b1 + n, tot);
+    } else {
+        const int o = min(c, no - 1);
+        const T tot = colsum32([&](int b) { return d2[(long)b * no + o]; });
+        if (rg == 0 && c < no) upd.apply(grad, off_b2 + o, tot);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Which path a batch of B takes.  The fused per-sample kernel is a chain of latency-bound phases
 // that costs the same from 1 to 256 samples (one workgroup per CU) and then grows by the full
@@ -1116,6 +1355,10 @@ __global__ __launch_bounds__(GB_THREADS) void grad_reduce_big(int B, int pout, i
 constexpr int BATCHED_MIN_B = 768;          // fused -> layer kernels where no tile fits
 constexpr int BATCHED_MAX_PARTIALS = 256;   // workgroups (= partial gradient rows) of conv_bwd_batch
 constexpr int BATCHED_SPLIT_ROWS = 256;     // up to here one thread of grad_reduce sums all rows of the batch
+#ifndef CCNN_SPLIT_MIN_B
+#define CCNN_SPLIT_MIN_B 1536
+#endif
+constexpr int SPLIT_MIN_B = CCNN_SPLIT_MIN_B;   // from here the batch sums are split over workgroups as well (grad_reduce_split)
 // FUSED: sample_fwd_bwd + grad_reduce.  TILE: tile_fwd_bwd + grad_reduce / grad_reduce_big.
 // LAYERS: the four layer kernels + grad_reduce / grad_reduce_big (shapes whose tile does not fit the LDS).
 // CCNN_MBGD_PATH=fused|batched|tile|layers overrides the choice by batch size (tests run every
@@ -1219,9 +1462,10 @@ template <typename T>
 struct MbgdWs {
     T *pool, *a1, *d1, *d2, *slab, *probs;
     // batched path only
-    T *dp, *gsum;
+    T *dp, *gsum, *part1;
     unsigned char *px;
     int *ctr;
+    unsigned *rctr;   // arrival counters of grad_reduce_split
     StepPath path;
     TilePlan plan;   // path == TILE
     static int partial_rows(int B, StepPath path, const TilePlan &tp)   // rows of the conv-gradient partials
@@ -1247,6 +1491,10 @@ struct MbgdWs {
             }
             b += align_up((size_t)d.nparams * sizeof(T));           // summed gradient (multi-GPU exchange)
             b += align_up(TRAIN_CTR_INTS * sizeof(int));
+            if (B >= SPLIT_MIN_B) {
+                b += align_up(SplitCfg<T>::partial_elems(B, d.pout) * sizeof(T));   // dW1 partials per batch slice
+                b += align_up(GS_CTR_INTS * sizeof(unsigned));
+            }
         }
         return b;
     }
@@ -1258,9 +1506,10 @@ struct MbgdWs {
         d1 = c.take<T>((size_t)B * H);
         d2 = c.take<T>((size_t)B * d.n_classes);
         probs = c.take<T>((size_t)B * d.n_classes);
-        dp = gsum = nullptr;
+        dp = gsum = part1 = nullptr;
         px = nullptr;
         ctr = nullptr;
+        rctr = nullptr;
         path = sc.path;
         plan = sc.plan;
         if (path == StepPath::FUSED) {
@@ -1274,6 +1523,10 @@ struct MbgdWs {
             }
             gsum = c.take<T>((size_t)d.nparams);
             ctr = c.take<int>(TRAIN_CTR_INTS);
+            if (B >= SPLIT_MIN_B) {
+                part1 = c.take<T>(SplitCfg<T>::partial_elems(B, d.pout));
+                rctr = c.take<unsigned>(GS_CTR_INTS);
+            }
         }
     }
 };
@@ -1343,7 +1596,7 @@ int mbgd_batched(const T *params, const T *cubes, const int *onehot, long first,
     const int G = MbgdWs<T>::partial_rows(B, w.path, w.plan);
     if (w.path == StepPath::TILE) {
         if (int e = tile_train<T, FLIP>(params, cubes, onehot, first, B, d, w.plan, w.pool, w.a1, w.d1, w.d2, probs,
-                                        loss_values, w.slab, st))
+                                        loss_values, w.slab, w.rctr, st))
             return e;
     } else {
     if (int e = train_forward<T, FLIP>(params, cubes, onehot, first, B, z, w.pool, w.px, w.a1, w.d1, w.d2, probs,
@@ -1365,21 +1618,32 @@ int mbgd_batched(const T *params, const T *cubes, const int *onehot, long first,
         const size_t smem = L.bytes(two ? 2 : 1);
         if (int e = allow_smem(kern, smem)) return e;
         launch("conv_bwd_batch", kern, dim3(G), dim3(CB_THREADS), smem, st, cubes, first, (const T *)w.dp,
-               (const T *)w.pool, (const unsigned char *)w.px, B, d.cube, d.re, d.mre, w.slab);
+               (const T *)w.pool, (const unsigned char *)w.px, B, d.cube, d.re, d.mre, w.slab, w.rctr);
         CCNN_LAUNCH_CHECK();
     }
     }
     if (B <= BATCHED_SPLIT_ROWS) return launch_grad_reduce<T>(B, d, w, G, grad, upd, cm, st);
-    // large batches: the batch is split inside the workgroups of one launch; across GPUs it stores
-    // the sum for the exchange + update kernel
+    // large batches: the batch is split inside the workgroups of one launch (and, from SPLIT_MIN_B
+    // samples, over workgroups as well); across GPUs the launch stores the sum for the exchange + update kernel
     {
-        const int nb_w1 = ((d.pout + 15) / 16 + 7) & ~7, nb_w0 = (F * K + F + 63) / 64;   // p tiles in whole groups of eight
+        const int nb_w0 = (F * K + F + 63) / 64;
         const int nb_w2 = (H * d.n_classes + 15) / 16, nb_b1 = (H + 15) / 16;
         const bool c13 = d.n_classes == CCNN_CLASSES;
-        launch("grad_reduce_big", c13 ? grad_reduce_big<T, CCNN_CLASSES> : grad_reduce_big<T, 0>,
-               dim3(7 * nb_w1 + nb_w0 + nb_w2 + nb_b1 + 1), dim3(GB_THREADS), 0, st, B, d.pout, d.off_w1, d.off_b1,
-               d.off_w2, d.off_b2, (const T *)w.pool, (const T *)w.a1, (const T *)w.d1, (const T *)w.d2,
-               (const T *)w.slab, G, nb_w1, nb_w0, nb_w2, nb_b1, cm ? w.gsum : grad, cm ? UpdateRule<T>{} : upd);
+        T *gout = cm ? w.gsum : grad;
+        const UpdateRule<T> rule = cm ? UpdateRule<T>{} : upd;
+        if (w.part1) {
+            const int npt = (d.pout + 15) / 16, nsl = SplitCfg<T>::slices(B), bs = SplitCfg<T>::slice_rows(B);
+            launch("grad_reduce_split", c13 ? grad_reduce_split<T, CCNN_CLASSES> : grad_reduce_split<T, 0>,
+                   dim3(npt * nsl + nb_w0 + nb_w2 + nb_b1 + 1), dim3(GS_THREADS), SplitCfg<T>::smem, st, B, d.pout, d.off_w1,
+                   d.off_b1, d.off_w2, d.off_b2, (const T *)w.pool, (const T *)w.a1, (const T *)w.d1, (const T *)w.d2,
+                   (const T *)w.slab, G, npt, nsl, bs, nb_w0, nb_w2, nb_b1, w.part1, w.rctr, gout, rule);
+        } else {
+            const int nb_w1 = ((d.pout + 15) / 16 + 7) & ~7;   // p tiles in whole groups of eight
+            launch("grad_reduce_big", c13 ? grad_reduce_big<T, CCNN_CLASSES> : grad_reduce_big<T, 0>,
+                   dim3(7 * nb_w1 + nb_w0 + nb_w2 + nb_b1 + 1), dim3(GB_THREADS), 0, st, B, d.pout, d.off_w1, d.off_b1,
+                   d.off_w2, d.off_b2, (const T *)w.pool, (const T *)w.a1, (const T *)w.d1, (const T *)w.d2,
+                   (const T *)w.slab, G, nb_w1, nb_w0, nb_w2, nb_b1, gout, rule);
+        }
         CCNN_LAUNCH_CHECK();
     }
     if (cm) {
@@ -1458,6 +1722,13 @@ int scratch_on_current_device(void **out)
     return 0;
 }
 }  // namespace
+
+#ifdef CCNN_SPLIT_TIMING
+extern "C" int ccnn_debug_split_ticks(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_split_ticks), sizeof(unsigned long long) * 1024 * 8);
+}
+#endif
 
 #ifdef CCNN_FB_TIMING
 extern "C" int ccnn_debug_fb_ticks(unsigned long long *out)

@@ -68,7 +68,10 @@ __host__ __device__ inline TileLayout tile_layout(int re, int mre, int nwv, int 
     L.kc = (ks + nch - 1) / nch;              // k-steps (of four positions) per delta-image chunk
     L.ldd = 4 * L.kc * LDWK;                  // one position-major delta tile [4 kc][16 filters]
     L.cube_pad = (conv_cube_pad(re) + 3) & ~3;
-    const int ns = nwv < 8 ? nwv : 8;                             // sample slots (cube, delta image, reduction row): one per sample
+    // sample slots (cube, delta image, reduction row): one per sample for tiles whose conv gradient is
+    // summed in the accumulators; larger tiles add all eight waves' accumulator rows, present or not
+    const int nsw = nwv < 8 ? nwv : 8;
+    const int ns = ms <= TILE_ACC_MS && ms < nsw ? ms : nsw;
     int b1 = WP_LEN;                                              // conv filters (forward)
     if (b1 < (nwv / 2) * 8 * TILE_ZN) b1 = (nwv / 2) * 8 * TILE_ZN;   // FC1 partial sums [K split][8][128]
     if (b1 < ms * pout) b1 = ms * pout;                           // delta x tanh' (the conv-bias path)
@@ -110,6 +113,13 @@ int tile_waves_env()
     const char *e = getenv("CCNN_TILE_WAVES");
     return e ? atoi(e) : 0;
 }
+// CCNN_TILE_MS=1..8 (diagnostics): samples per tile instead of the count tile_plan would choose
+static int tile_ms_env()
+{
+    const char *e = getenv("CCNN_TILE_MS");
+    const int v = e ? atoi(e) : 0;
+    return v >= 1 && v <= 8 ? v : 0;
+}
 
 template <typename T>
 bool tile_plan_waves(int B, const ccnn_dims_t &d, int forced_waves, TilePlan *out)
@@ -119,6 +129,7 @@ bool tile_plan_waves(int B, const ccnn_dims_t &d, int forced_waves, TilePlan *ou
     int want = (B + 255) / 256;
     if (want < 1) want = 1;
     if (want > 8) want = 8;
+    if (const int forced = tile_ms_env()) want = forced;
     for (int ms = want; ms >= 1; ms--) {
         for (int nwv = tile_max_waves<T>(ms, forced_waves); nwv >= 4; nwv >>= 1) {
             if (ms > nwv) continue;
@@ -171,13 +182,19 @@ struct Quad<double> {
 };
 
 // NO: the class count when it is the reference's 13 (compile-time then), 0 for any other (d.n_classes).
+// (Tried and not kept: an eight-wave instantiation held to 128 registers so that TWO workgroups of
+// four samples share a compute unit, one's latency phases under the other's matrix phases - 52.1
+// against 38.5 us at 2048 samples of 103 bands: half tiles read W1 twice as often and their conv
+// gradient runs 22 full 16-wide products per k-step where a full tile runs 11 and 12 short ones.)
 template <typename T, bool FLIP, int NO, int NWV>
 __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ params, const T *__restrict__ cubes,
                                                     const int *__restrict__ onehot, long first, int B, int ms, int nch,
                                                     ccnn_dims_t d, T *__restrict__ pool_g, T *__restrict__ a1_g,
                                                     T *__restrict__ d1_g, T *__restrict__ d2_g, T *__restrict__ probs_g,
-                                                    double *__restrict__ loss_values, T *__restrict__ part)
+                                                    double *__restrict__ loss_values, T *__restrict__ part,
+                                                    unsigned *zero_ctr)
 {
+    if (zero_ctr && blockIdx.x == 0 && threadIdx.x < TRAIN_ZERO_INTS) zero_ctr[threadIdx.x] = 0;   // for the batch sums that follow
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Vec16<T>::type V;
     constexpr int VW = Vec16<T>::W;
@@ -193,7 +210,7 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
     T *pl = base + L.pl, *a1s = base + L.a1, *d1s = base + L.d1, *w2s = base + L.w2, *b1s = base + L.b1v;
     T *b2s = base + L.b2v, *es = base + L.es, *d2s = base + L.d2;
     T *bs = base + L.bs, *rb = base + L.rb;
-    const bool slot = wave < NS;            // this wave stages a sample slot's cube
+    const bool slot = wave < NS && (ms > TILE_ACC_MS || wave < ms);   // this wave stages a sample slot's cube
     T *cube = base + L.cube + (slot ? wave : 0) * L.cube_pad;
     unsigned char *px = reinterpret_cast<unsigned char *>(smem + L.px_off);
 
@@ -848,7 +865,7 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
 template <typename T, bool FLIP>
 int tile_train(const T *params, const T *cubes, const int *onehot, long first, int B, const ccnn_dims_t &d,
                const TilePlan &plan, T *pool, T *a1, T *d1, T *d2, T *probs, double *loss_values, T *part,
-               hipStream_t st)
+               unsigned *zero_ctr, hipStream_t st)
 {
     const bool c13 = d.n_classes == CCNN_CLASSES;
     auto kern = plan.nwv == 8 ? (c13 ? tile_fwd_bwd<T, FLIP, CCNN_CLASSES, 8> : tile_fwd_bwd<T, FLIP, 0, 8>)
@@ -858,15 +875,15 @@ int tile_train(const T *params, const T *cubes, const int *onehot, long first, i
     }
     if (int e = allow_smem(kern, plan.smem)) return e;
     launch("tile_fwd_bwd", kern, dim3(plan.tiles), dim3(64 * plan.nwv), plan.smem, st, params, cubes, onehot, first, B,
-           plan.ms, plan.nch, d, pool, a1, d1, d2, probs, loss_values, part);
+           plan.ms, plan.nch, d, pool, a1, d1, d2, probs, loss_values, part, zero_ctr);
     CCNN_LAUNCH_CHECK();
     return 0;
 }
 template int tile_train<float, true>(const float *, const float *, const int *, long, int, const ccnn_dims_t &,
                                      const TilePlan &, float *, float *, float *, float *, float *, double *, float *,
-                                     hipStream_t);
+                                     unsigned *, hipStream_t);
 template int tile_train<double, false>(const double *, const double *, const int *, long, int, const ccnn_dims_t &,
                                        const TilePlan &, double *, double *, double *, double *, double *, double *,
-                                       double *, hipStream_t);
+                                       double *, unsigned *, hipStream_t);
 
 }  // namespace ccnn
