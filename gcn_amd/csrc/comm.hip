@@ -182,7 +182,10 @@ hipError_t pool_acquire(int device, size_t bytes, void **out)
     }
     void *p = nullptr;
     // uncached: peers write it over xGMI behind the local L2's back
-    const hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
+    // (CCNN_COMM_ALLOC=plain, diagnostics only: ordinary device memory - tells "the uncached attribute
+    // outlives the allocation" from "a peer's mapping outlives its close" in tools/comm_reuse_probe.py)
+    static const bool plain = getenv("CCNN_COMM_ALLOC") && !strcmp(getenv("CCNN_COMM_ALLOC"), "plain");
+    const hipError_t e = plain ? hipMalloc(&p, bytes) : hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
     if (e != hipSuccess) return e;
     g_pool.push_back({p, bytes, device, true});
     *out = p;
@@ -191,9 +194,21 @@ hipError_t pool_acquire(int device, size_t bytes, void **out)
 
 void pool_release(void *ptr)
 {
+    // CCNN_COMM_POOL=free (diagnostics only): give the buffer back to the allocator, the behaviour the
+    // pool exists to avoid - tools/comm_reuse_probe.py uses it to reproduce what then goes wrong
+    static const bool do_free = getenv("CCNN_COMM_POOL") && !strcmp(getenv("CCNN_COMM_POOL"), "free");
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    for (PooledBuffer &b : g_pool)
-        if (b.ptr == ptr) b.in_use = false;
+    for (size_t i = 0; i < g_pool.size(); i++) {
+        if (g_pool[i].ptr != ptr) continue;
+        if (do_free) {
+            const hipError_t e = hipFree(ptr);
+            if (comm_debug()) fprintf(stderr, "[ccnn-comm] free ptr=%p bytes=%zu rc=%d\n", ptr, g_pool[i].bytes, (int)e);
+            g_pool.erase(g_pool.begin() + i);
+        } else {
+            g_pool[i].in_use = false;
+        }
+        return;
+    }
 }
 
 }  // namespace

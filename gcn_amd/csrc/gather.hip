@@ -231,9 +231,13 @@ int gather_impl(const T *scene, const int *idx9, long n, int x, int y, int z, T 
         order = GatherWs(ws, n).order;
     }
     long blocks = ((n + GS - 1) / GS + 7) / 8 * 8;   // a multiple of 8: one slice of the list per XCD
-    if (blocks > GATHER_GRID) blocks = GATHER_GRID;
+    static const long grid_env = getenv("CCNN_GATHER_GRID") ? atol(getenv("CCNN_GATHER_GRID")) : 0;     // diagnostics
+    static const long split_env = getenv("CCNN_GATHER_SPLIT") ? atol(getenv("CCNN_GATHER_SPLIT")) : 0;
+    const long grid_cap = grid_env > 0 ? grid_env : GATHER_GRID;
+    if (blocks > grid_cap) blocks = grid_cap;
     const int npass = (z + GBANDS - 1) / GBANDS;
-    long split = 3 * GATHER_GRID / (2 * blocks);   // enough workgroups to fill the chip on short lists
+    long split = 3 * grid_cap / (2 * blocks);   // enough workgroups to fill the chip on short lists
+    if (split_env > 0) split = split_env;
     split = split < 1 ? 1 : split > npass ? npass : split;
     {
         launch("gather_tile", gather_tile<T>, dim3((unsigned)blocks, (unsigned)split), dim3(256), 0, st, scene, idx9,

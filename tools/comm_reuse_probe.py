@@ -4,7 +4,13 @@ data-parallel step against the CPU oracle, the step itself against the oracle gr
 and the inputs against their host copies.  This is the reproducer of what a freed exchange buffer does
 to the owner's later allocations (with buffers freed at destroy: wrong fp64 gradients at B = 32, the
 first workspace above 1 MB, in 8 of 12 runs; with the library's buffer pool: 0 of 10).
-    torchrun --nproc-per-node 2 tools/comm_reuse_probe.py     (WS_EARLY=1: one workspace allocated first)"""
+    torchrun --nproc-per-node 2 tools/comm_reuse_probe.py     (WS_EARLY=1: one workspace allocated first)
+CCNN_COMM_POOL=free makes the library free its buffers at destroy (the failing configuration);
+CCNN_COMM_ALLOC=plain allocates them as ordinary instead of uncached device memory.  On a bad local
+gradient the probe runs the same gradient once more into the suspect workspace and once into a
+workspace that was allocated before any exchange buffer existed, and reports where the two
+workspaces differ: address ranges, the region (pool / a1 / d1 / d2 / probs / conv-gradient rows) and
+whether the differing 8-byte words look like the exchange's tagged words (payload | sequence << 32)."""
 import os, sys
 import numpy as np, torch, torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,6 +24,7 @@ torch.cuda.set_device(0)
 z = 103
 d = L.dims(z)
 nbad = 0
+GOOD = ops.Workspace(); GOOD.get(96 << 20)     # allocated before any exchange buffer exists: never on recycled pages
 WS = None
 if os.environ.get("WS_EARLY"):       # one workspace for everything, allocated before any exchange buffer exists
     WS = ops.Workspace(); WS.get(64 << 20)
@@ -35,7 +42,7 @@ for dtype in (torch.float32, torch.float64):
         _, _, g_ref = orc.mbgd_step(p0_h.copy(), cubes_h, oh_h, 0, B, z, npdt(0.0))
         p0, cubes, oh = torch.from_numpy(p0_h).cuda(), torch.from_numpy(cubes_h).cuda(), torch.from_numpy(oh_h).cuda()
         def local_err():
-            g, _ = ops.mbgd_grad(p0, cubes, oh, 0, B, z, workspace=WS)
+            g, _ = ops.mbgd_grad(p0, cubes, oh, 0, B, z, workspace=WS)      # WS None: a fresh block per call, dropped after it
             torch.cuda.synchronize()
             return float(np.abs(g.cpu().numpy() - g_ref).max() / np.abs(g_ref).max())
         e_a = local_err()
@@ -58,6 +65,28 @@ for dtype in (torch.float32, torch.float64):
         if max(e_a, e_b, e_dp) > tol or not ok_in or comm.status():
             nbad += 1
             e_c = local_err()
+            if e_a > tol or e_b > tol:
+                # the same gradient into a fresh (suspect) workspace and into the early one: diff the rows the kernels leave behind
+                es = 4 if dtype == torch.float32 else 8
+                nb = L.load().ccnn_mbgd_workspace_bytes(B, z, es)
+                # (the allocator hands the block that the failed call has just dropped to the next request of its size)
+                sus = ops.Workspace(); sus.get(nb); sus.buf.fill_(0x5a)
+                GOOD.buf[:nb].fill_(0x5a)
+                gs_, _ = ops.mbgd_grad(p0, cubes, oh, 0, B, z, workspace=sus)
+                gg_, _ = ops.mbgd_grad(p0, cubes, oh, 0, B, z, workspace=GOOD)
+                torch.cuda.synchronize()
+                a = sus.buf[:nb].cpu().numpy().view(np.uint64); b = GOOD.buf[:nb].cpu().numpy().view(np.uint64)
+                diff = np.flatnonzero(a != b)
+                al = lambda v: (v + 255) // 256 * 256
+                offs, o = {}, 0
+                for nm, cnt in (("pool", B * d.pout), ("a1", B * 100), ("d1", B * 100), ("d2", B * 13), ("probs", B * 13), ("slab", B * 3440)):
+                    offs[nm] = (o, o + cnt * es); o = al(o + cnt * es)
+                where = {nm: int(((diff * 8 >= lo) & (diff * 8 < hi)).sum()) for nm, (lo, hi) in offs.items()}
+                eg = float(np.abs(gs_.cpu().numpy() - g_ref).max() / np.abs(g_ref).max()); eo = float(np.abs(gg_.cpu().numpy() - g_ref).max() / np.abs(g_ref).max())
+                print(f"[{rank}]   suspect workspace {sus.buf.data_ptr():#x}+{nb:#x} grad err {eg:.1e}; early workspace {GOOD.buf.data_ptr():#x} grad err {eo:.1e}; "
+                      f"{len(diff)} of {len(a)} 8-byte words differ, by region {where}", flush=True)
+                for i in diff[:6]:
+                    print(f"[{rank}]     word {int(i) * 8:#x}: suspect {int(a[i]):#018x} (as f64 {a[i:i+1].view(np.float64)[0]:.6g}) early {int(b[i]):#018x} ({b[i:i+1].view(np.float64)[0]:.6g})", flush=True)
             print(f"[{rank}] {dtype} it {it} via={via} B={B}: local before {e_a:.1e}, after {e_b:.1e}, again {e_c:.1e}; in-step {e_dp:.1e}; inputs intact {ok_in}; status {comm.status()}", flush=True)
         dist.barrier()
     comm.close()
