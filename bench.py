@@ -46,6 +46,7 @@ def kernel_work(d, z):
         # dW1 = pool^T d1, dW2 = a1^T d2
         "grad_reduce": ("mfma", fc1 + 2.0 * 1300),
         "grad_reduce_big": ("mfma", fc1 + 2.0 * 1300),
+        "grad_reduce_split": ("mfma", fc1 + 2.0 * 1300),
         "conv_pool_fwd": ("mfma", conv),
         "fc_head_fwd": ("mfma", fc1 + 2.0 * 1300),
         # the batched training path: conv fwd | FC1 + FC2 fwd + delta1 | delta at the pooled features | conv gradient
@@ -124,7 +125,7 @@ def kernel_rows(rep, d, z, pixels, passes=None, world=1, es=4):
     return rows
 
 
-TRAIN_KERNELS = ("sample_fwd_bwd", "tile_fwd_bwd", "grad_reduce", "grad_reduce_big", "update_f32_kernel", "allreduce_apply", "conv_pool_fwd_train",
+TRAIN_KERNELS = ("sample_fwd_bwd", "tile_fwd_bwd", "grad_reduce", "grad_reduce_big", "grad_reduce_split", "update_f32_kernel", "allreduce_apply", "conv_pool_fwd_train",
                  "fc_head_fwd_train", "dpool_bwd", "conv_bwd_batch")
 STEP_PATHS = {0: "fused per-sample kernel", 1: "sample-tile kernel", 2: "batched layer kernels"}   # ccnn_mbgd_path
 
@@ -546,20 +547,24 @@ def main():
     log(f"timing {args.steps} steps, mode {mode}")
     dt = timed(args.steps, args.warmup)
     train_pps = world * B * args.steps / dt
-    # how much a single step's time scatters around that mean: the same steps again (untimed for
-    # `value`), each bracketed by events on the launch stream (this rank's GPU only)
-    nsp = max(20, min(args.steps, 200))
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(nsp + 1)]
+    # how much the step time scatters around that mean: the same steps again (untimed for `value`), an
+    # event on the launch stream after every GROUP steps (an event per step would add its own couple
+    # of microseconds to every interval), this rank's GPU only
+    GROUP = 10
+    ngr = max(10, min(args.steps, 400) // GROUP)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(ngr + 1)]
     fence()
     evs[0].record()
-    for i in range(nsp):
-        step(args.warmup + i)
-        evs[i + 1].record()
+    for g in range(ngr):
+        for i in range(GROUP):
+            step(args.warmup + g * GROUP + i)
+        evs[g + 1].record()
     fence()
-    per = np.array([evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(nsp)])
-    spread = {"steps": nsp, "median_us": round(float(np.median(per)), 2), "p10_us": round(float(np.percentile(per, 10)), 2),
-              "p90_us": round(float(np.percentile(per, 90)), 2), "max_us": round(float(per.max()), 2),
-              "what": "per-step intervals between events recorded after each step of a second, untimed pass"}
+    per = np.array([evs[g].elapsed_time(evs[g + 1]) * 1e3 / GROUP for g in range(ngr)])
+    spread = {"groups": ngr, "steps_per_group": GROUP, "median_us": round(float(np.median(per)), 2),
+              "p10_us": round(float(np.percentile(per, 10)), 2), "p90_us": round(float(np.percentile(per, 90)), 2),
+              "max_us": round(float(per.max()), 2),
+              "what": "per-step time of groups of ten steps (events between the groups) in a second, untimed pass"}
     log(f"timed region done: {dt / args.steps * 1e6:.2f} us/step")
     assert torch.isfinite(params).all(), "training diverged"
     replicas_identical = True

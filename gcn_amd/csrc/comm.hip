@@ -152,15 +152,18 @@ void log_handle(const char *what, int rank, int peer, const void *ptr, const voi
 }
 
 // Exchange buffers live as long as the process: ccnn_comm_destroy hands a buffer back to this
-// list and a later ccnn_comm_create on the same device takes it again (zeroed).  Memory that peer
-// PROCESSES have had mapped is not safe to give back to the allocator while they are alive:
-// measured with two ranks on one GPU (tools/comm_reuse_probe.py), after hipFree of a first set of
-// buffers the next large allocation of the owner - a training workspace - produced gradients that
-// were wrong by up to 20 % and changed from call to call, with the inputs intact and no wait timed
-// out, in 8 of 12 runs; 0 of 6 with the buffers kept, 0 of 6 with the workspace allocated before
-// the first set existed.  Every close and free had returned success and every set had its own
-// addresses and handles, so what still reaches the freed pages was not identified; not freeing
-// them avoids the question.
+// list and a later ccnn_comm_create on the same device takes it again (zeroed).  Uncached memory
+// (hipDeviceMallocUncached) must not go back to the allocator while the process runs: the next
+// ordinary allocation that lands on the freed range computes wrong results.  Measured with two ranks
+// on one GPU (tools/comm_reuse_probe.py, CCNN_COMM_POOL=free): after hipFree of a first set of
+// buffers the owner's next large allocation - a training workspace on the freed address range -
+// gives LOCAL gradients (no exchange involved) wrong by up to 20 %, call after call, with the inputs
+// intact and no wait timed out, in 4 of 6 rank-runs; the same gradient is exact in any other block,
+// and in the same block once a fill has overwritten all of it, so nothing keeps writing there (no
+// late peer store, no tagged words).  With the same buffers allocated as ordinary device memory
+// (CCNN_COMM_ALLOC=plain) and freed: 0 of 6; with the buffers kept: 0 of 6.  The fault follows the
+// page attribute, not the peers' mappings; keeping the buffers avoids it, and so would ordinary
+// memory - which peers could not write coherently over xGMI.
 struct PooledBuffer {
     void *ptr;
     size_t bytes;

@@ -343,8 +343,8 @@ int ccnn_comm_set_exchange(ccnn_comm_t *comm, int via_owner);
  * (ccnn_comm_disconnect; returns the first unmap error, if any), and only when ALL ranks
  * have done so may any rank destroy its own comm (ccnn_comm_destroy; it disconnects first if
  * that was not done).  The exchange buffer itself is not given back to the allocator: the
- * library keeps it for the process's next ccnn_comm_create on that device (memory that other
- * processes have had mapped proved unsafe to reuse for anything else while they live). */
+ * library keeps it for the process's next ccnn_comm_create on that device (uncached memory that is
+ * freed and handed out again proved unsafe for its next user on this runtime). */
 int ccnn_comm_disconnect(ccnn_comm_t *comm);
 int ccnn_comm_destroy(ccnn_comm_t *comm);
 /* buf[k] = sum over ranks of buf[k], in place. */
