@@ -141,6 +141,7 @@ def main():
         # a batch large enough for the sample-tile kernel and the one-pass batch sums, whose total
         # goes through the stand-alone exchange + update kernel
         assert comm._self_test_step(z, B=600), "data-parallel step of a large batch"
+        assert comm._self_test_step(z, B=1600), "data-parallel step of a batch whose sums are split over workgroups"
         # both forms of the in-step exchange, whatever the default for this many ranks is:
         # everybody writes to everybody / reduce at an owner rank that sends the total round
         for via_owner in (True, False, True):

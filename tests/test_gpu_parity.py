@@ -11,6 +11,7 @@ import torch
 import oracle as orc
 import parity
 import synth
+from gcn_amd import lib as L
 from gcn_amd import ops, prep
 
 pytestmark = pytest.mark.gpu
@@ -356,6 +357,34 @@ def test_mbgd_large_batches_match_oracle(dtype, z, B, lr, monkeypatch):
             lv = ops.mbgd_step(p_gpu, c_gpu, o_gpu, i0 * B, B, z, lr, workspace=ws)
             assert relerr(lv.cpu().numpy(), refs[i0][0]) < TOL[dtype], (path, i0)
             parity.assert_groups(p_gpu.cpu().numpy(), refs[i0][1], d, TOL[dtype], f"parameters, path {path}, step {i0}")
+
+
+def test_split_batch_sums_do_not_depend_on_what_the_workspace_held(monkeypatch):
+    """From 1536 samples the batch sums are split over workgroups that count their arrivals in the
+    caller's workspace: the kernel before them clears the counters, so a workspace full of ones
+    (or of an earlier, differently sized call's rows) gives the same bits as a zeroed one - on the
+    sample-tile path and on the layer kernels."""
+    z, B = 103, 1600
+    params, cubes, onehot = make_problem(z, B, 31, np.float32)
+    c_gpu, o_gpu = dev(cubes), dev(onehot)
+    for path in ("tile", "layers"):
+        monkeypatch.setenv("CCNN_MBGD_PATH", path)
+        outs = []
+        for fill in (0x00, 0xff, None):
+            ws = ops.Workspace()
+            nbytes = L.load().ccnn_mbgd_workspace_bytes(2048, z, 4)
+            ws.get(nbytes).fill_(fill if fill is not None else 0)
+            p_gpu = dev(params)
+            if fill is None:      # a larger batch first: its rows and counters stay behind
+                ops.mbgd_step(dev(params), dev(np.concatenate([cubes, cubes[:448]])), dev(np.concatenate([onehot, onehot[:448]])),
+                              0, 2048, z, 0.001, workspace=ws)
+            lv = ops.mbgd_step(p_gpu, c_gpu, o_gpu, 0, B, z, 0.002, workspace=ws)
+            outs.append((p_gpu.cpu(), lv.cpu()))
+        for p_o, lv_o in outs[1:]:
+            assert torch.equal(p_o, outs[0][0]) and torch.equal(lv_o, outs[0][1]), path
+    p_ref = params.copy()
+    lv_ref, _, _ = orc.mbgd_step(p_ref, cubes, onehot, 0, B, z, np.float32(0.002), want_grad=False)
+    parity.assert_groups(outs[0][0].numpy(), p_ref, orc.dims(z), 1e-5, "split batch sums")
 
 
 def test_adagrad_update_matches_oracle():
