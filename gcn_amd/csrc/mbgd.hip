@@ -54,6 +54,11 @@ __device__ unsigned long long g_fb_ticks[32];
 #ifndef CCNN_STOP_PHASE
 #define CCNN_STOP_PHASE 0   // diagnostic builds only: end sample_fwd_bwd after phase N
 #endif
+// The forward convolution of sample_fwd_bwd on the packed filter image (filters 16..19 as one chain of
+// 57 k-steps per 64 positions instead of a second 16-wide tile with twelve empty columns).
+#ifndef CCNN_FB_PACKED
+#define CCNN_FB_PACKED(T) (sizeof(T) == 8)
+#endif
 
 namespace ccnn {
 
@@ -74,7 +79,7 @@ __host__ __device__ inline FusedLayout fused_layout(int re, int mre)
     const int pout = F * mre;
     L.ks = (re + 3) >> 2;
     L.ldd = 4 * L.ks * LDWK;   // one position-major delta tile [4 ks][16 filters]
-    const int wl_len = 2 * L.ldd > WL_LEN ? 2 * L.ldd : WL_LEN;   // filters, later the scattered deltas
+    const int wl_len = 2 * L.ldd > WP_LEN ? 2 * L.ldd : WP_LEN;   // filters (tile of 16 + packed tile), later the scattered deltas
     const int a0_len = 32 * H;   // FC1 partial sums [G][100], G <= 32 row groups
     int o = 0;
     L.cube = o; o += up4(conv_cube_pad(re));
@@ -190,6 +195,7 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
                                                       T *__restrict__ slab, int d_rows)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool PACKED = CCNN_FB_PACKED(T);
     const FusedLayout L = fused_layout<T>(d.re, d.mre);
     T *base = reinterpret_cast<T *>(smem);
     T *cube = base + L.cube, *wl = base + L.wl, *a0 = base + L.a0, *pl = base + L.pl, *dp = base + L.dp;
@@ -218,34 +224,64 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
 #pragma unroll
         for (int u = 0; u < NCREG; u++) creg[u] = src[min(u * NT + tid, d.cube - 1)];   // clamped, unconditional
     }
-    constexpr int NWREG = (F * K + NT - 1) / NT;
+    // The conv filters.  PACKED: as conv_pool_chain wants them (ccnn_device.h: filters 0..15 tap-major,
+    // then the packed tile of filters 16..19) - thread t owns elements t, t + NT, .. of the IMAGE and
+    // fetches the filter value (or a zero) that belongs there, so there is no zeroing pass and no
+    // barrier between one and a scatter.  Otherwise: two plain tap-major tiles, every thread fetches
+    // filter elements and scatters them behind a zeroing pass and a barrier.  (The fp32 reference walks
+    // the filter backwards in the forward pass only, gcn_mbgd_fp32.cu:241-243.)
+    static_assert(LDWK == 16, "the image element -> (tap, filter) split below");
+    constexpr int NWREG = PACKED ? (WP_LEN + NT - 1) / NT : (F * K + NT - 1) / NT;
     T wreg[NWREG];
+    unsigned wok = 0;   // PACKED, bit u: element u holds a filter value (else a zero)
 #pragma unroll
     for (int u = 0; u < NWREG; u++) {
         const int e = u * NT + tid;
-        wreg[u] = params[d.off_w0 + (e < F * K ? e : F * K - 1)];   // clamped: loads stay unconditional
+        if constexpr (PACKED) {
+            int f, kk;
+            if (e < WL_TILE) {
+                kk = e >> 4;
+                f = e & 15;
+            } else {
+                const int x = e - WL_TILE, c = x & 15;
+                f = 16 + (c & 3);
+                kk = (x >> 4) - WSTEP * (c >> 2);   // column c = shift c / 4 of filter 16 + c % 4
+            }
+            const bool ok = e < WP_LEN && kk >= 0 && kk < K;
+            wreg[u] = params[d.off_w0 + (ok ? f * K + (FLIP ? K - 1 - kk : kk) : 0)];   // clamped: loads stay unconditional
+            wok |= (unsigned)ok << u;
+        } else {
+            wreg[u] = params[d.off_w0 + (e < F * K ? e : F * K - 1)];   // clamped: loads stay unconditional
+        }
     }
     const T *W2 = params + d.off_w2;
+    constexpr int a0_half = 16 * H;          // the FC1 partial sums [G][100] use at most 16 row groups of the 32 the region holds
     const int o8 = tid >> 3, j8 = tid & 7;   // output layer: one output per 8 lanes, 8 partial sums each
     constexpr int NP8 = (H + 7) / 8;         // products per partial sum
-    T w2f[NP8], w2b[OMAX];
+    // The output layer's weights go through LDS (the upper half of the FC1 partial-sum region, which
+    // the partial sums never reach): three loads per thread.  Held in registers by the threads that
+    // use them they were 29 loads per thread for ALL threads, and a load instruction costs a wave its
+    // slot in the memory pipeline whatever its lanes carry - 0.35 us of the prologue's issue time.
+    constexpr int NW2 = (H * OMAX + NT - 1) / NT;
+    T w2r[NW2];
 #pragma unroll
-    for (int k = 0; k < NP8; k++) {
-        const int i = min(j8 + 8 * k, H - 1);   // hidden unit of the k-th partial product
-        w2f[k] = W2[min(o8, no - 1) + i * no];
-    }
-#pragma unroll
-    for (int k = 0; k < OMAX; k++) w2b[k] = W2[min(k, no - 1) + min(tid, H - 1) * no];   // past the class count: never used
+    for (int u = 0; u < NW2; u++) w2r[u] = W2[min(u * NT + tid, H * no - 1)];
+    T *w2s = a0 + a0_half;
     const T b1v = params[d.off_b1 + min(tid, H - 1)];
     const T b2v = params[d.off_b2 + min(o8, no - 1)];
     const T bias0 = params[d.off_b0 + col];
-    const T bias1 = params[d.off_b0 + min(16 + col, F - 1)];
+    const T biasx = params[d.off_b0 + (PACKED ? 16 + (col & 3) : min(16 + col, F - 1))];   // second tile's columns
     FB_TICK(11);
     for (int e = d.cube + tid; e < conv_cube_pad(re); e += NT) cube[e] = 0;
-    // zeros the filter scatter below does not overwrite: the second tile (filters 20..31) and tap 171 of the first
-    for (int e = WL_TILE - LDWK + tid; e < WL_LEN; e += NT) wl[e] = 0;
+    if constexpr (!PACKED) {
+        // zeros the filter scatter below does not overwrite: the second tile (filters 20..31) and tap 171 of the first
+        for (int e = WL_TILE - LDWK + tid; e < WL_LEN; e += NT) wl[e] = 0;
+    }
     FB_TICK(12);
     if (tid < no) lab[tid] = lab_g;   // the first use of a loaded value: after the zeroing, which needs none
+#pragma unroll
+    for (int u = 0; u < NW2; u++)
+        if (u * NT + tid < H * no) w2s[u * NT + tid] = w2r[u];
     FB_TICK(13);
 #pragma unroll
     for (int u = 0; u < NCREG; u++) {
@@ -253,15 +289,23 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
         if (e < d.cube) cube[e] = creg[u];
     }
     FB_TICK(14);
-    __syncthreads();
-    FB_TICK(15);
+    if constexpr (PACKED) {
 #pragma unroll
-    for (int u = 0; u < NWREG; u++) {
-        const int e = u * NT + tid;
-        if (e < F * K) {
-            const int f = e / K, k = e - f * K;
-            // the fp32 reference walks the filter backwards in the forward pass (gcn_mbgd_fp32.cu:241-243)
-            wl[wl_index(f, FLIP ? K - 1 - k : k)] = wreg[u];
+        for (int u = 0; u < NWREG; u++) {
+            const int e = u * NT + tid;
+            if (e < WP_LEN) wl[e] = (wok >> u & 1) ? wreg[u] : T(0);
+        }
+        FB_TICK(15);
+    } else {
+        __syncthreads();
+        FB_TICK(15);
+#pragma unroll
+        for (int u = 0; u < NWREG; u++) {
+            const int e = u * NT + tid;
+            if (e < F * K) {
+                const int f = e / K, k = e - f * K;
+                wl[wl_index(f, FLIP ? K - 1 - k : k)] = wreg[u];
+            }
         }
     }
     __syncthreads();
@@ -269,10 +313,20 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
 #if CCNN_STOP_PHASE == 1
     return;
 #endif
-    conv_pool_tiles<T>(cube, 0, 1, wl, re, bias0, bias1, lane, wave, [&](int, int f, int m, T v, int bt) {
-        pl[f * mre + m] = v;
-        px[f * mre + m] = bt;
-    }, NW, NW > 4);
+    if constexpr (PACKED) {
+        // one chain per wave: the position tiles of filters 0..15, then the packed tile's chains
+        for (int job = wave; job < conv_chains(re); job += NW) {
+            conv_pool_chain<T>(cube, wl, re, job, bias0, biasx, lane, [&](int f, int m, T v, int bt) {
+                pl[f * mre + m] = v;
+                px[f * mre + m] = bt;
+            });
+        }
+    } else {
+        conv_pool_tiles<T>(cube, 0, 1, wl, re, bias0, biasx, lane, wave, [&](int, int f, int m, T v, int bt) {
+            pl[f * mre + m] = v;
+            px[f * mre + m] = bt;
+        }, NW, NW > 4);
+    }
     __syncthreads();
     FB_TICK(2);
 #if CCNN_STOP_PHASE == 2
@@ -288,6 +342,7 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
     constexpr int NQ = H / VW;
     constexpr int QL = NQ <= 32 ? 32 : 64;
     constexpr int G = NT / QL;
+    static_assert(G * H <= a0_half && a0_half + H * OMAX <= 32 * H, "FC1 partial sums and the output layer's weights share a0");
     const int q = tid & (QL - 1), g = tid / QL;
     const bool qv = q < NQ;
     const int qc = qv ? q : NQ - 1;
@@ -353,7 +408,7 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
 #pragma unroll
         for (int k = 0; k < NP8; k++) {
             const int i = j8 + 8 * k;
-            if (i < H) mid = mid + w2f[k] * a1s[i];
+            if (i < H) mid = mid + w2s[min(o8, no - 1) + i * no] * a1s[i];
         }
         mid += __shfl_xor(mid, 4);
         mid += __shfl_xor(mid, 2);
@@ -378,23 +433,10 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
         // bp_fully_connect(out -> hidden), gcn_mbgd_fp64.cu:416-434: class-wide tree
         T prod[OMAX];
 #pragma unroll
-        for (int o = 0; o < OMAX; o++) prod[o] = w2b[o] * d2s[o];
+        for (int o = 0; o < OMAX; o++) prod[o] = w2s[min(o, no - 1) + tid * no] * d2s[o];   // past the class count: never used
         const T dv = tree_n(prod, no) * (1 + a) * (1 - a);
         d1s[tid] = dv;
         if (lead) d1_g[row * H + tid] = dv;
-    }
-    // the loss (a log and an exp per class, then the ordered sum) is nobody's input: an idle wave
-    // computes it here, lane o the terms of class o
-    if (tid >= NT - 64) {
-        const int o = tid - (NT - 64);
-        T ta = 0, tb = 0;
-        int lb = 0;
-        if (o < no) {
-            lb = lab[o];
-            loss_terms(ps[o], lb, &ta, &tb);
-        }
-        const double loss = loss_sum_lanes(ta, tb, lb, no);
-        if (o == 0 && lead) loss_values[row] = loss;
     }
     __syncthreads();
     FB_TICK(7);
@@ -461,6 +503,20 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
     else
         conv_bwd_tiles<T, NW>(cube, wl, L.ldd, L.ks, re, out, lane, wave);
     FB_TICK(9);
+    // the loss (a log and an exp per class, then the ordered sum) is nobody's input: the last wave,
+    // which has the fewest tap tiles of the conv gradient, computes it here at the end, lane o the
+    // terms of class o (ps and lab are not reused by the phases in between)
+    if (lead && tid >= NT - 64) {
+        const int o = tid - (NT - 64);
+        T ta = 0, tb = 0;
+        int lb = 0;
+        if (o < no) {
+            lb = lab[o];
+            loss_terms(ps[o], lb, &ta, &tb);
+        }
+        const double loss = loss_sum_lanes(ta, tb, lb, no);
+        if (o == 0) loss_values[row] = loss;
+    }
     if (tid < F / SPLIT) {
         // bias path: at a winner the conv output equals the pooled value, so the
         // reference's second tanh' (gcn_mbgd_fp64.cu:487-488) needs only pl
