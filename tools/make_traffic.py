@@ -39,7 +39,7 @@ def main():
     src = sys.argv[1].rstrip("/")
     records = []
     for fname, batch, kernels in (("pmc_hbm.csv", 128, ("sample_fwd_bwd", "grad_reduce", "step_fused")),
-                                  ("pmc_hbm_b2048.csv", 2048, ("tile_fwd_bwd", "grad_reduce_big"))):
+                                  ("pmc_hbm_b2048.csv", 2048, ("tile_fwd_bwd", "grad_reduce_big", "grad_reduce_split"))):
         path = os.path.join(src, fname)
         if not os.path.exists(path):
             continue
