@@ -108,6 +108,14 @@ def load():
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # torch first: its wheel carries its own copy of the HIP runtime, and a process must hold only one -
+    # loaded after torch, this library binds to the runtime torch already brought in (same soname);
+    # loaded before it, the two would each initialise a runtime of their own and this library's
+    # launches would fail with "no ROCm-capable device" on tensors torch allocated
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIG.items():
         fn = getattr(lib, name)   # AttributeError if the symbol is not exported
