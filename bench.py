@@ -165,9 +165,11 @@ def train_rate(params_h, cubes, onehot_d, z, B, steps, workload, profile=True):
     lv = torch.zeros((nb, B), dtype=torch.float64, device=cubes.device)
     lr = 0.04 * min(1.0, 128.0 / B) if es == 4 else 0.5
 
+    stepper = ops.MbgdStepper(p, cubes, onehot_d, B, z, loss_values=lv, workspace=ws)
+
     def step(i):
         b = i % nb
-        ops.mbgd_step(p, cubes, onehot_d, b * B, B, z, lr, loss_values=lv[b], workspace=ws)
+        stepper.step(b * B, lr, b)
     for i in range(min(steps, 30)):
         step(i)
     dt = timed_steps(step, steps)
@@ -443,14 +445,18 @@ def main():
             comm.set_exchange(m == "instep_owner")
     log(f"exchange set up: mode {mode}" + (f", ranks share a device: {comm.shared_device}" if comm is not None else ""))
 
+    # the step's unchanging arguments resolved once (ops.MbgdStepper): one foreign call per step
+    st_local = ops.MbgdStepper(params, cubes, onehot_d, B, z, loss_values=loss_ring, workspace=ws)
+    st_dp = ops.MbgdStepper(params, cubes, onehot_d, B, z, loss_values=loss_ring, workspace=ws, comm=comm) if comm is not None else None
+
     def step(i):
         b = i % nb
         if not use_dist:
             # gradient + update fused (nothing has to happen in between on one GPU)
-            ops.mbgd_step(params, cubes, onehot_d, b * B, B, z, lr, loss_values=loss_ring[b], workspace=ws)
+            st_local.step(b * B, lr, b)
         elif mode in ("instep", "instep_owner"):
             # two launches: the reduction kernel trades its sums with the other ranks and updates
-            ops.mbgd_step(params, cubes, onehot_d, b * B, B, z, lr, loss_values=loss_ring[b], workspace=ws, comm=comm)
+            st_dp.step(b * B, lr, b)
         else:
             ops.mbgd_grad(params, cubes, onehot_d, b * B, B, z, grad=grad, loss_values=loss_ring[b], workspace=ws)
             if mode == "standalone":

@@ -143,3 +143,32 @@ def test_fit_mbgd_keep_tail_batch():
         assert abs(hist.loss[ep] - tot / T) <= 1e-11 * abs(tot / T)
         _, cur = sched.step(tot / T, cur)
     assert relerr(got["params"].cpu().numpy(), p) < 1e-11
+
+
+@pytest.mark.parametrize("dtype,B", [(np.float32, 24), (np.float64, 20), (np.float32, 300)])
+def test_stepper_equals_mbgd_step(dtype, B):
+    """ops.MbgdStepper (arguments resolved once, one foreign call per step) leaves the same bits as
+    ops.mbgd_step: parameters after four steps and every step's per-sample losses; out-of-range
+    steps are refused before anything is launched."""
+    z = 60
+    rng = np.random.default_rng(4)
+    n = 4 * B
+    cubes = torch.from_numpy(rng.random((n, 9 * z)).astype(dtype)).cuda()
+    oh = np.zeros((n, 13), dtype=np.int32)
+    oh[np.arange(n), rng.integers(0, 13, n)] = 1
+    oh = torch.from_numpy(oh).cuda()
+    orc.srand(3)
+    p0 = orc.init_params_f32(z) if dtype == np.float32 else orc.init_params_f64(z, orc.dims(z).pout * B)
+    p_a, p_b = torch.from_numpy(p0).cuda(), torch.from_numpy(p0).cuda()
+    ring = torch.zeros((4, B), dtype=torch.float64, device="cuda")
+    lr = 0.01 if dtype == np.float32 else 0.5
+    st = ops.MbgdStepper(p_a, cubes, oh, B, z, loss_values=ring)
+    for i in range(4):
+        st.step(i * B, lr, i)
+        lv = ops.mbgd_step(p_b, cubes, oh, i * B, B, z, lr)
+        assert torch.equal(ring[i], lv), i
+    torch.cuda.synchronize()
+    assert torch.equal(p_a, p_b) and not torch.equal(p_a, torch.from_numpy(p0).cuda())
+    for bad_first, bad_row in ((n - B + 1, 0), (-1, 0), (0, 4)):
+        with pytest.raises(ValueError):
+            st.step(bad_first, lr, bad_row)

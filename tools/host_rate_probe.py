@@ -19,3 +19,13 @@ for n in (50, 2000):
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     print(f"n={n}: enqueue {(t1 - t0) / n * 1e6:.1f} us/step, total {(t2 - t0) / n * 1e6:.1f} us/step")
+st = ops.MbgdStepper(p, cubes, oh, B, z, loss_values=lv, workspace=ws)
+for i in range(200): st.step((i % 8) * B, 0.0)
+torch.cuda.synchronize()
+for n in (50, 2000):
+    t0 = time.perf_counter()
+    for i in range(n): st.step((i % 8) * B, 0.0)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"MbgdStepper n={n}: enqueue {(t1 - t0) / n * 1e6:.1f} us/step, total {(t2 - t0) / n * 1e6:.1f} us/step")
