@@ -76,7 +76,7 @@ def kernel_source_digest():
     return h.hexdigest()[:16]
 
 
-def committed_traffic(workload, batch, kernel):
+def committed_traffic(workload, batch, kernel, dtype="f32"):
     """(HBM bytes per launch of `kernel`, where the figure comes from).  The bytes are those of the
     committed PMC passes (rocprofv3 --pmc cannot run inside this process): None when no pass was
     recorded for this workload and batch, and None - with the reason - when the kernels' sources
@@ -85,7 +85,7 @@ def committed_traffic(workload, batch, kernel):
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             doc = json.load(f)
         for rec in doc["records"]:
-            if (rec["workload"], rec["batch"], rec["kernel"]) == (workload, batch, kernel):
+            if (rec["workload"], rec["batch"], rec["kernel"], rec.get("dtype", "f32")) == (workload, batch, kernel, dtype):
                 where = f"committed {doc.get('summaries', 'profiles/')} (profiles/traffic.json), kernels @{doc.get('kernel_source_digest')}"
                 try:
                     now = kernel_source_digest()
@@ -96,7 +96,7 @@ def committed_traffic(workload, batch, kernel):
                 return rec["hbm_bytes_per_launch"], where
     except (OSError, KeyError, ValueError):
         pass
-    return None, "no PMC pass recorded for this workload and batch"
+    return None, "no PMC pass recorded for this workload, batch and precision"
 
 
 def kernel_rows(rep, d, z, pixels, passes=None, world=1, es=4):
@@ -130,13 +130,13 @@ TRAIN_KERNELS = ("sample_fwd_bwd", "tile_fwd_bwd", "grad_reduce", "grad_reduce_b
 STEP_PATHS = {0: "fused per-sample kernel", 1: "sample-tile kernel", 2: "batched layer kernels"}   # ccnn_mbgd_path
 
 
-def dominant(rows, workload, B):
+def dominant(rows, workload, B, dtype="f32"):
     train_k = [k for k in TRAIN_KERNELS if k in rows]
     if not train_k:
         return None
     dom = max(train_k, key=lambda k: rows[k]["avg_us"])
     k = rows[dom]
-    traffic, source = committed_traffic(workload, B, dom)
+    traffic, source = committed_traffic(workload, B, dom, dtype)
     return {"kernel": dom, "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"], "unit": k["unit"],
             "frac": k["frac"], "traffic": traffic, "traffic_source": source, "avg_us": k["avg_us"]}
 
@@ -184,7 +184,7 @@ def train_rate(params_h, cubes, onehot_d, z, B, steps, workload, profile=True):
         torch.cuda.synchronize()
         L.profile_enable(False)
         rows = kernel_rows(L.profile_report(), d, z, {k: B for k in TRAIN_KERNELS}, es=es)
-        out["roofline"] = dominant(rows, workload if es == 4 else workload + "_f64", B)
+        out["roofline"] = dominant(rows, workload, B, "f32" if es == 4 else "f64")
         out["kernels"] = {k: {"avg_us": v["avg_us"], "frac": v["frac"]} for k, v in rows.items()}
     return out
 

@@ -3,8 +3,8 @@
 
     make_traffic.py profiles/r3a_bench
 
-Reads pmc_hbm.csv (the headline run: Pavia-U shape, B = 128) and pmc_hbm_b2048.csv (B = 2048) as
-tools/profile_bench.sh leaves them, and stamps the digest of the training kernels' sources
+Reads pmc_hbm.csv (the headline run: Pavia-U shape, B = 128), pmc_hbm_b2048.csv, pmc_hbm_f32_b512.csv
+and pmc_hbm_f64_b100.csv (the canonical fp64 trainer's batch) as tools/profile_bench.sh leaves them, and stamps the digest of the training kernels' sources
 (bench.py: kernel_source_digest) so that bench.py reports `roofline.traffic` only for the build
 that was profiled.  hbm_bytes_per_launch = (2 FETCH_SIZE + WRITE_SIZE) KiB: gfx950 tallies a
 128-byte read request as 64 bytes, which over-counts narrow loads - an upper bound."""
@@ -38,16 +38,18 @@ def counters(path):
 def main():
     src = sys.argv[1].rstrip("/")
     records = []
-    for fname, batch, kernels in (("pmc_hbm.csv", 128, ("sample_fwd_bwd", "grad_reduce", "step_fused")),
-                                  ("pmc_hbm_b2048.csv", 2048, ("tile_fwd_bwd", "grad_reduce_big", "grad_reduce_split"))):
+    small = ("sample_fwd_bwd", "grad_reduce", "step_fused")
+    large = ("tile_fwd_bwd", "grad_reduce_big", "grad_reduce_split")
+    for fname, batch, dtype, kernels in (("pmc_hbm.csv", 128, "f32", small), ("pmc_hbm_b2048.csv", 2048, "f32", large),
+                                         ("pmc_hbm_f64_b100.csv", 100, "f64", small), ("pmc_hbm_f32_b512.csv", 512, "f32", large)):
         path = os.path.join(src, fname)
         if not os.path.exists(path):
             continue
         for full, c in counters(path).items():
-            m = re.match(r"ccnn::(\w+)<float", full)
+            m = re.match(r"ccnn::(\w+)<" + ("float" if dtype == "f32" else "double"), full)
             if not m or m.group(1) not in kernels or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
                 continue
-            records.append({"workload": "pavia_u", "batch": batch, "kernel": m.group(1), "instance": full,
+            records.append({"workload": "pavia_u", "batch": batch, "dtype": dtype, "kernel": m.group(1), "instance": full,
                             "fetch_size_kib": c["FETCH_SIZE"], "write_size_kib": c["WRITE_SIZE"],
                             "hbm_bytes_per_launch": int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)})
     doc = {
