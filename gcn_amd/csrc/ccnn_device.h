@@ -404,6 +404,43 @@ __device__ __forceinline__ void conv_pool_tiles(const T *cube, int cube_stride, 
     }
 }
 
+// The same for a workgroup that owns the filters fbase .. fbase + nf - 1 (nf <= 16) of ONE sample:
+// only the first tile of wl exists, its columns 0 .. nf - 1 hold those filters (columns past them
+// may hold anything: a column's values never leave the column, and nothing is put for it), tap 171
+// is zero.  One job per position tile.  put(filter, m, value, winning position).
+template <typename T, typename Put>
+__device__ __forceinline__ void conv_pool_own(const T *cube, const T *wl, int re, T bias, int fbase, int nf, int lane,
+                                              int wave, int nwaves, Put put)
+{
+    const int col = lane & 15, kq = lane >> 4;
+    const int mt = conv_mtiles(re);
+    const T *bq[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) bq[u] = wl + kq * LDWK + ((col ^ kq) ^ (4 * u));
+    constexpr int KMAIN = KSTEPS0 & ~3;
+    for (int tile = wave; tile < mt; tile += nwaves) {
+        const T *ap = cube + WSTEP * (tile * 16 + col) + kq;
+        typename Mma<T>::acc_t acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};   // two chains: even / odd k-steps
+        for (int s = 0; s < KMAIN; s += 4) {
+            T a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                a[u] = ap[4 * (s + u)];
+                b[u] = bq[u][4 * (s + u) * LDWK];
+            }
+            acc = Mma<T>::mma(a[0], b[0], acc);
+            acc2 = Mma<T>::mma(a[1], b[1], acc2);
+            acc = Mma<T>::mma(a[2], b[2], acc);
+            acc2 = Mma<T>::mma(a[3], b[3], acc2);
+        }
+#pragma unroll
+        for (int u = 0; u < KSTEPS0 - KMAIN; u++) acc = Mma<T>::mma(ap[4 * (KMAIN + u)], bq[u][4 * (KMAIN + u) * LDWK], acc);
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[r] += acc2[r];
+        pool_tile(acc, bias, fbase + col, col < nf, tile * 16, re, lane, put);
+    }
+}
+
 // One MFMA chain of KS k-steps as two interleaved accumulators (even / odd k-steps).  The
 // operands of the next four k-steps are fetched before the MFMAs of the current four are
 // issued, so a wave always has LDS reads in flight behind its matrix instructions.

@@ -23,10 +23,13 @@
 // reads W1 once per tile) or, where no tile fits the LDS, the layer kernels below
 // (conv_pool_fwd<TRAIN> + fc_head_fwd<TRAIN> of forward.hip, dpool_bwd, conv_bwd_batch), and
 // grad_reduce_big for the batch sums; step_path() chooses.
-#include <mutex>
+#include <unistd.h>
 
+#include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "ccnn_device.h"
 #include "comm.h"
@@ -170,6 +173,68 @@ __device__ __forceinline__ void conv_bwd_tiles(const T *cube, const T *delta, in
 }
 
 // ---------------------------------------------------------------------------
+// Trade of one value per thread between the two workgroups of a sample (sample_fwd_bwd, FS): every
+// 32 bits of the value travel in an 8-byte word together with the launch's tag, so the reader knows
+// from the word itself that it is this launch's (no fence, no flag, no ordering between stores); the
+// accesses are relaxed agent-scope atomics (performed at the L2 / memory side, never served from a
+// CU's cache).  The reader clears the words it has consumed - the partner wrote them before the
+// reader could see them and does not touch them again in this launch - so a launch always finds the
+// words of the launch before it empty, whatever its tag (a captured launch replays with the tag it
+// was captured with).  `tag` is never 0.  The wait is bounded (2 s of the 100 MHz clock; a partner
+// is dispatched right behind its workgroup): when it runs out the sum becomes a NaN, which reaches
+// the loss and every parameter - a step that went wrong cannot look like one that did not.
+constexpr unsigned long long PAIR_WAIT_TICKS = 200000000ull;
+template <typename T>
+struct PairWords {
+    static constexpr int N = sizeof(T) / 4;   // tagged words per value
+};
+__device__ __forceinline__ unsigned long long pair_word(unsigned bits, unsigned tag)
+{
+    return ((unsigned long long)bits << 32) | tag;
+}
+// Publishes `own` at out[0 .. N), takes the partner's value from in[0 .. N) and returns the sum of
+// the two in the order (first workgroup's) + (second workgroup's): the same bits in both.
+__device__ __forceinline__ float pair_sum(float own, unsigned long long *out, unsigned long long *in, unsigned tag, bool first)
+{
+    __hip_atomic_store(out, pair_word(__float_as_uint(own), tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = wall_clock64();
+    unsigned long long v;
+    unsigned spins = 0;
+    while ((unsigned)(v = __hip_atomic_load(in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != tag) {
+        if ((++spins & 255) == 0 && wall_clock64() - t0 > PAIR_WAIT_TICKS) {
+            v = pair_word(0x7fc00000u, tag);
+            break;
+        }
+    }
+    __hip_atomic_store(in, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float other = __uint_as_float((unsigned)(v >> 32));
+    return first ? own + other : other + own;
+}
+__device__ __forceinline__ double pair_sum(double own, unsigned long long *out, unsigned long long *in, unsigned tag, bool first)
+{
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(own);
+    __hip_atomic_store(out, pair_word((unsigned)(bits >> 32), tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(out + 1, pair_word((unsigned)bits, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = wall_clock64();
+    unsigned long long hi, lo;
+    unsigned spins = 0;
+    while (true) {
+        hi = __hip_atomic_load(in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lo = __hip_atomic_load(in + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)hi == tag && (unsigned)lo == tag) break;
+        if ((++spins & 255) == 0 && wall_clock64() - t0 > PAIR_WAIT_TICKS) {
+            hi = pair_word(0x7ff80000u, tag);
+            lo = pair_word(0u, tag);
+            break;
+        }
+    }
+    __hip_atomic_store(in, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(in + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double other = __longlong_as_double((long long)((hi >> 32 << 32) | (lo >> 32)));
+    return first ? own + other : other + own;
+}
+
+// ---------------------------------------------------------------------------
 // NT threads per workgroup (one workgroup per sample, one per CU): the per-sample chain is
 // latency-bound, and its two walks over W1 are limited by the bytes a CU keeps in flight, so
 // more waves shorten them even though most other phases cannot use the extra threads.
@@ -177,14 +242,19 @@ __device__ __forceinline__ void conv_bwd_tiles(const T *cube, const T *delta, in
 // loops and its 13-wide tree cost what they cost before the count became a run-time property),
 // 0 for any other count (read from d).
 // SPLIT = 2 (small batches, which leave half of the chip idle): two workgroups per sample, on one
-// XCD (blocks i and i + 8).  Both run the whole forward pass - splitting it would need a trade of
-// the FC1 partial sums between workgroups, which costs what it saves - and each takes the
-// backward pass of ten filters: its half of the second W1 walk, its filters' conv gradient.  No
-// workgroup waits for another, and every value is computed exactly as with one workgroup.
+// XCD (blocks i and i + 8), each with the backward pass of ten filters: its half of the second W1
+// walk, its filters' conv gradient.  FS = false: both run the whole forward pass, no workgroup waits
+// for another, and every value is computed exactly as with one workgroup.  FS = true (the host asks
+// for it when all workgroups of the launch fit the chip at once): the forward pass is split as well -
+// a workgroup convolves and pools its ten filters only and walks only their rows of W1; the hundred
+// partial sums of the hidden layer are traded through `xch` (pair_sum: 0.6-0.8 us), after which both
+// hold the same z1 bit for bit and carry on as before.  The forward walk is bound by what the L2s
+// deliver to all workgroups together, so half the rows are worth 0.9 us of 2.9 at 103 bands in fp32
+// and 3.0 of 8.4 at 176 bands in fp64, the conv phase another 0.5 - 2 us.
 // WPE: waves per SIMD the register allocation must leave room for (2: one workgroup per CU, all
 // the registers the chain wants; 4: two workgroups per CU, for batches of more samples than CUs,
 // whose second round then runs beside the first instead of after it).
-template <typename T, bool FLIP, int NT, int NO, int SPLIT, int WPE = 2>
+template <typename T, bool FLIP, int NT, int NO, int SPLIT, int WPE = 2, bool FS = false>
 __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ params,
                                                       const T *__restrict__ cubes,
                                                       const int *__restrict__ onehot, long first,
@@ -192,10 +262,13 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
                                                       T *__restrict__ a1_g, T *__restrict__ d1_g,
                                                       T *__restrict__ d2_g, T *__restrict__ probs_g,
                                                       double *__restrict__ loss_values,
-                                                      T *__restrict__ slab, int d_rows)
+                                                      T *__restrict__ slab, int d_rows,
+                                                      unsigned long long *__restrict__ xch, unsigned xtag)
 {
+    static_assert(!FS || SPLIT == 2, "the forward pass splits over the two workgroups of a sample");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr bool PACKED = CCNN_FB_PACKED(T);
+    constexpr bool PACKED = CCNN_FB_PACKED(T) && !FS;   // a half's ten filters are one plain tile
+    constexpr int NFO = FS ? F / 2 : F;                // filters this workgroup convolves
     const FusedLayout L = fused_layout<T>(d.re, d.mre);
     T *base = reinterpret_cast<T *>(smem);
     T *cube = base + L.cube, *wl = base + L.wl, *a0 = base + L.a0, *pl = base + L.pl, *dp = base + L.dp;
@@ -231,7 +304,8 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
     // filter elements and scatters them behind a zeroing pass and a barrier.  (The fp32 reference walks
     // the filter backwards in the forward pass only, gcn_mbgd_fp32.cu:241-243.)
     static_assert(LDWK == 16, "the image element -> (tap, filter) split below");
-    constexpr int NWREG = PACKED ? (WP_LEN + NT - 1) / NT : (F * K + NT - 1) / NT;
+    constexpr int NWREG = PACKED ? (WP_LEN + NT - 1) / NT : (NFO * K + NT - 1) / NT;
+    const int fown = FS ? half * NFO : 0;   // the first of them
     T wreg[NWREG];
     unsigned wok = 0;   // PACKED, bit u: element u holds a filter value (else a zero)
 #pragma unroll
@@ -251,7 +325,7 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
             wreg[u] = params[d.off_w0 + (ok ? f * K + (FLIP ? K - 1 - kk : kk) : 0)];   // clamped: loads stay unconditional
             wok |= (unsigned)ok << u;
         } else {
-            wreg[u] = params[d.off_w0 + (e < F * K ? e : F * K - 1)];   // clamped: loads stay unconditional
+            wreg[u] = params[d.off_w0 + fown * K + (e < NFO * K ? e : NFO * K - 1)];   // clamped: loads stay unconditional
         }
     }
     const T *W2 = params + d.off_w2;
@@ -269,11 +343,13 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
     T *w2s = a0 + a0_half;
     const T b1v = params[d.off_b1 + min(tid, H - 1)];
     const T b2v = params[d.off_b2 + min(o8, no - 1)];
-    const T bias0 = params[d.off_b0 + col];
+    const T bias0 = params[d.off_b0 + (FS ? fown + min(col, NFO - 1) : col)];
     const T biasx = params[d.off_b0 + (PACKED ? 16 + (col & 3) : min(16 + col, F - 1))];   // second tile's columns
     FB_TICK(11);
     for (int e = d.cube + tid; e < conv_cube_pad(re); e += NT) cube[e] = 0;
-    if constexpr (!PACKED) {
+    if constexpr (FS) {
+        if (tid < LDWK) wl[WL_TILE - LDWK + tid] = 0;   // tap 171 (columns 10..15 of the tile: see conv_pool_own)
+    } else if constexpr (!PACKED) {
         // zeros the filter scatter below does not overwrite: the second tile (filters 20..31) and tap 171 of the first
         for (int e = WL_TILE - LDWK + tid; e < WL_LEN; e += NT) wl[e] = 0;
     }
@@ -302,8 +378,8 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
 #pragma unroll
         for (int u = 0; u < NWREG; u++) {
             const int e = u * NT + tid;
-            if (e < F * K) {
-                const int f = e / K, k = e - f * K;
+            if (e < NFO * K) {
+                const int f = e / K, k = e - f * K;   // FS: column f of the one tile holds filter fown + f
                 wl[wl_index(f, FLIP ? K - 1 - k : k)] = wreg[u];
             }
         }
@@ -313,7 +389,12 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
 #if CCNN_STOP_PHASE == 1
     return;
 #endif
-    if constexpr (PACKED) {
+    if constexpr (FS) {
+        conv_pool_own<T>(cube, wl, re, bias0, fown, NFO, lane, wave, NW, [&](int f, int m, T v, int bt) {
+            pl[f * mre + m] = v;
+            px[f * mre + m] = bt;
+        });
+    } else if constexpr (PACKED) {
         // one chain per wave: the position tiles of filters 0..15, then the packed tile's chains
         for (int job = wave; job < conv_chains(re); job += NW) {
             conv_pool_chain<T>(cube, wl, re, job, bias0, biasx, lane, [&](int f, int m, T v, int bt) {
@@ -332,8 +413,12 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
 #if CCNN_STOP_PHASE == 2
     return;
 #endif
-    if (lead)
+    if constexpr (FS) {
+        const int o0 = half * (pout / 2);   // F is even: a half is ten whole filters
+        for (int o = tid; o < pout / 2; o += NT) pool_g[row * pout + o0 + o] = pl[o0 + o];
+    } else if (lead) {
         for (int o = tid; o < pout; o += NT) pool_g[row * pout + o] = pl[o];
+    }
 
     // ---- FC1 forward: z1[n] = sum_p pool[p] W1[n + 100 p] ---------------------------
     // 16-byte vectors along n; QL lanes per W1 row (25 or 50 of them active), G row groups.
@@ -357,7 +442,11 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
     // A running row number costs three instructions per row; rows past the end wrap onto valid
     // ones, so the loads stay unconditional without a clamp.
     unsigned wbase = 0, wlen = (unsigned)pout;   // the rows a walk covers: wbase + (0 .. wlen - 1)
-    unsigned p_run = (unsigned)((g + rot) % pout);
+    if (FS) {
+        wlen = (unsigned)(pout / 2);
+        wbase = half * wlen;
+    }
+    unsigned p_run = (unsigned)((g + rot % (int)wlen) % (int)wlen);
     auto next_row = [&]() {
         const unsigned p = p_run, t = p_run + G;
         p_run = min(t, t - wlen);   // t < wlen: the difference wraps to a huge value
@@ -369,7 +458,7 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
     };
     {
         V acc = {};
-        for (int pb = 0; pb < pout; pb += G * UFF) {
+        for (int pb = 0; pb < (int)wlen; pb += G * UFF) {
             V w[UFF];
             unsigned prow[UFF];
 #pragma unroll
@@ -379,7 +468,7 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
             }
 #pragma unroll
             for (int u = 0; u < UFF; u++) {
-                const T x = (qv && pb + u * G + g < pout) ? pl[prow[u]] : T(0);
+                const T x = (qv && pb + u * G + g < (int)wlen) ? pl[prow[u]] : T(0);
                 acc += w[u] * x;
             }
         }
@@ -395,6 +484,12 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
         T zsum = 0;
 #pragma unroll
         for (int gg = 0; gg < G; gg++) zsum = zsum + z1p[gg * H + tid];
+        if constexpr (FS) {
+            // zsum covers this workgroup's ten filters: add the partner's
+            constexpr int XW = PairWords<T>::N;
+            unsigned long long *xrow = xch + (size_t)row * (2 * H * XW);
+            zsum = pair_sum(zsum, xrow + (half * H + tid) * XW, xrow + ((half ^ 1) * H + tid) * XW, xtag, lead);
+        }
         a = act(zsum + b1v);   // gcn_mbgd_fp64.cu:302
         a1s[tid] = a;
         if (lead) a1_g[row * H + tid] = a;
@@ -1514,9 +1609,35 @@ inline bool split_samples(int B)
     if (forced >= 0) return forced != 0;
     return 16 * ((B + 7) / 8) <= fb_cus();
 }
+// The forward pass splits over a sample's two workgroups as well when every workgroup of the launch
+// has a compute unit to itself from the start: partners wait for each other, and a partner that
+// could only start after its workgroup had finished would never come.  CCNN_FB_FSPLIT=0 (tests,
+// measurements) keeps the whole forward pass in both.
+inline bool split_forward(int B)
+{
+    static const bool off = [] {
+        const char *s = getenv("CCNN_FB_FSPLIT");
+        return s && atoi(s) == 0;
+    }();
+    return !off && split_samples(B) && 16 * ((B + 7) / 8) <= fb_cus();
+}
+// The tag of a launch's pair_sum words: a process-wide counter that starts at a value derived from
+// the clock and the process id (what an earlier process left in memory does not carry this one's
+// tags) and skips 0, the value of a consumed word.
+inline unsigned next_pair_tag()
+{
+    static std::atomic<unsigned> ctr{(unsigned)std::chrono::steady_clock::now().time_since_epoch().count() * 2654435761u ^
+                                     ((unsigned)getpid() << 16)};
+    unsigned t;
+    do t = ctr.fetch_add(1, std::memory_order_relaxed);
+    while (t == 0);
+    return t;
+}
 template <typename T>
 struct MbgdWs {
     T *pool, *a1, *d1, *d2, *slab, *probs;
+    unsigned long long *xch;   // fused path, forward pass split: [rows][2][H][PairWords] tagged words
+    static size_t xch_words(int B) { return (size_t)8 * ((B + 7) / 8) * 2 * H * PairWords<T>::N; }
     // batched path only
     T *dp, *gsum, *part1;
     unsigned char *px;
@@ -1538,6 +1659,7 @@ struct MbgdWs {
         const TilePlan &tp = sc.plan;
         if (path == StepPath::FUSED) {
             b += align_up((size_t)B * (F * K + F) * sizeof(T));     // per-sample conv gradient tiles
+            if (split_forward(B)) b += align_up(xch_words(B) * 8);
         } else {
             const int G = partial_rows(B, path, tp);
             b += align_up((size_t)G * (F * K + F) * sizeof(T));     // per-workgroup conv gradient partials
@@ -1563,6 +1685,7 @@ struct MbgdWs {
         d2 = c.take<T>((size_t)B * d.n_classes);
         probs = c.take<T>((size_t)B * d.n_classes);
         dp = gsum = part1 = nullptr;
+        xch = nullptr;
         px = nullptr;
         ctr = nullptr;
         rctr = nullptr;
@@ -1570,6 +1693,7 @@ struct MbgdWs {
         plan = sc.plan;
         if (path == StepPath::FUSED) {
             slab = c.take<T>((size_t)B * (F * K + F));
+            if (split_forward(B)) xch = c.take<unsigned long long>(xch_words(B));
         } else {
             const int G = partial_rows(B, path, plan);
             slab = c.take<T>((size_t)G * (F * K + F));
@@ -1729,13 +1853,15 @@ int mbgd_impl(const T *params, const T *cubes, const int *onehot, long first, in
     const bool c13 = d.n_classes == CCNN_CLASSES;
     static const int dense_env = getenv("CCNN_FB_DENSE") ? atoi(getenv("CCNN_FB_DENSE")) : -1;   // diagnostics
     const bool dense = dense_env >= 0 ? dense_env != 0 : (!split && sizeof(T) == 4 && B > fb_cus());
-    const auto fb = split   ? (c13 ? sample_fwd_bwd<T, FLIP, FB_THREADS, CCNN_CLASSES, 2> : sample_fwd_bwd<T, FLIP, FB_THREADS, 0, 2>)
+    const bool fs = w.xch != nullptr;
+    const auto fb = fs      ? (c13 ? sample_fwd_bwd<T, FLIP, FB_THREADS, CCNN_CLASSES, 2, 2, true> : sample_fwd_bwd<T, FLIP, FB_THREADS, 0, 2, 2, true>)
+                    : split ? (c13 ? sample_fwd_bwd<T, FLIP, FB_THREADS, CCNN_CLASSES, 2> : sample_fwd_bwd<T, FLIP, FB_THREADS, 0, 2>)
                     : dense ? (c13 ? sample_fwd_bwd<T, FLIP, FB_THREADS, CCNN_CLASSES, 1, 4> : sample_fwd_bwd<T, FLIP, FB_THREADS, 0, 1, 4>)
                             : (c13 ? sample_fwd_bwd<T, FLIP, FB_THREADS, CCNN_CLASSES, 1> : sample_fwd_bwd<T, FLIP, FB_THREADS, 0, 1>);
     if (int e = allow_smem(fb, L.bytes)) return e;
     {
         launch("sample_fwd_bwd", fb, dim3(split ? 16 * ((B + 7) / 8) : B), dim3(FB_THREADS), L.bytes, st, params, cubes,
-               onehot, first, d, w.pool, w.a1, w.d1, w.d2, probs, loss_values, w.slab, B);
+               onehot, first, d, w.pool, w.a1, w.d1, w.d2, probs, loss_values, w.slab, B, w.xch, fs ? next_pair_tag() : 0u);
     }
     CCNN_LAUNCH_CHECK();
     return launch_grad_reduce<T>(B, d, w, B, grad, upd, cm, st);

@@ -387,6 +387,64 @@ def test_split_batch_sums_do_not_depend_on_what_the_workspace_held(monkeypatch):
     parity.assert_groups(outs[0][0].numpy(), p_ref, orc.dims(z), 1e-5, "split batch sums")
 
 
+@pytest.mark.parametrize("dtype,z,B,lr", [(np.float32, 103, 128, 0.04), (np.float64, 176, 100, 0.5), (np.float32, 200, 37, 0.04)])
+def test_pair_exchange_does_not_depend_on_what_the_workspace_held(dtype, z, B, lr):
+    """At the reference's batch sizes the two workgroups of a sample trade their halves of the hidden
+    layer's sums through tagged words in the caller's workspace.  A reader clears what it has read and
+    every launch has a tag of its own, so a workspace of zeros, of ones, of random bytes, or one that an
+    earlier, differently sized call has used gives the same bits - three steps in a row each, and the
+    result is the oracle's."""
+    params, cubes, onehot = make_problem(z, 3 * B, 41, dtype)
+    c_gpu, o_gpu = dev(cubes), dev(onehot)
+    es = np.dtype(dtype).itemsize
+    assert L.load().ccnn_mbgd_path(B, z, es) == 0
+    nbytes = L.load().ccnn_mbgd_workspace_bytes(128, z, es)
+    outs = []
+    for fill in (0x00, 0xff, "random", "used"):
+        ws = ops.Workspace()
+        buf = ws.get(nbytes)
+        if fill == "random":
+            buf.copy_(torch.randint(0, 256, (buf.numel(),), dtype=torch.uint8, generator=torch.Generator().manual_seed(5)).to(buf.device))
+        elif fill == "used":
+            buf.fill_(0)
+            ops.mbgd_step(dev(params), c_gpu, o_gpu, 0, min(128, B + 19), z, lr, workspace=ws)
+        else:
+            buf.fill_(fill)
+        p_gpu = dev(params)
+        lvs = [ops.mbgd_step(p_gpu, c_gpu, o_gpu, i0 * B, B, z, lr, workspace=ws).cpu() for i0 in range(3)]
+        outs.append((p_gpu.cpu(), torch.stack(lvs)))
+    for p_o, lv_o in outs[1:]:
+        assert torch.equal(p_o, outs[0][0]) and torch.equal(lv_o, outs[0][1])
+    p_ref = params.copy()
+    for i0 in range(3):
+        orc.mbgd_step(p_ref, cubes, onehot, i0 * B, B, z, dtype(lr), want_grad=False)
+    parity.assert_groups(outs[0][0].numpy(), p_ref, orc.dims(z), TOL[dtype] * 3, "three steps through the pair exchange")
+
+
+def test_forward_pass_split_over_a_pair_agrees_with_the_unsplit_form(monkeypatch):
+    """CCNN_FB_FSPLIT=0 keeps the whole forward pass in both workgroups of a sample (the form for
+    launches that do not fit the chip at once); the split form adds the two halves of the hidden
+    layer's sums in another order and must agree to rounding."""
+    z, B = 103, 96
+    params, cubes, onehot = make_problem(z, B, 43, np.float32)
+    c_gpu, o_gpu = dev(cubes), dev(onehot)
+    # (the switch is read once per process: the unsplit form runs in a child process)
+    import subprocess, sys, tempfile, os as _os
+    p_gpu = dev(params)
+    lv = ops.mbgd_step(p_gpu, c_gpu, o_gpu, 0, B, z, 0.04)
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(_os.path.join(td, "in.npz"), params=params, cubes=cubes, onehot=onehot)
+        code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); from gcn_amd import ops; d = np.load(%r);"
+                "p = torch.from_numpy(d['params']).cuda(); lv = ops.mbgd_step(p, torch.from_numpy(d['cubes']).cuda(),"
+                "torch.from_numpy(d['onehot']).cuda(), 0, %d, %d, 0.04); np.savez(%r, p=p.cpu().numpy(), lv=lv.cpu().numpy())"
+                % (_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), _os.path.join(td, "in.npz"), B, z, _os.path.join(td, "out.npz")))
+        env = dict(_os.environ, CCNN_FB_FSPLIT="0")
+        subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=240)
+        out = np.load(_os.path.join(td, "out.npz"))
+    parity.assert_groups(p_gpu.cpu().numpy(), out["p"], orc.dims(z), 1e-5, "split against unsplit forward pass")
+    assert relerr(lv.cpu().numpy(), out["lv"]) < 1e-5
+
+
 def test_adagrad_update_matches_oracle():
     rng = np.random.default_rng(1)
     n = 5000
