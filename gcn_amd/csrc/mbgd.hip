@@ -54,6 +54,9 @@ __device__ unsigned long long g_fb_ticks[32];
 #ifndef CCNN_FB_UFB
 #define CCNN_FB_UFB 1    // rounds of 16 W1 rows in flight in the backward walk
 #endif
+#ifndef CCNN_FB_PREW
+#define CCNN_FB_PREW 1   // the backward walk's first round of W1 rows is fetched before the head
+#endif
 #ifndef CCNN_STOP_PHASE
 #define CCNN_STOP_PHASE 0   // diagnostic builds only: end sample_fwd_bwd after phase N
 #endif
@@ -290,6 +293,7 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
     // Issue every global load this phase needs (filters, cube, and the small output-layer
     // operands used much later) before touching LDS, so one memory round trip covers them.
     constexpr int NW = NT / 64;
+    static_assert(NW >= 2, "the conv-bias path and the loss have a wave each");
     constexpr int NCREG = (NB * CCNN_MAX_BANDS + NT - 1) / NT;   // the cube comes from HBM, cold: first in the queue
     T creg[NCREG];
     {
@@ -345,83 +349,8 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
     const T b2v = params[d.off_b2 + min(o8, no - 1)];
     const T bias0 = params[d.off_b0 + (FS ? fown + min(col, NFO - 1) : col)];
     const T biasx = params[d.off_b0 + (PACKED ? 16 + (col & 3) : min(16 + col, F - 1))];   // second tile's columns
-    FB_TICK(11);
-    for (int e = d.cube + tid; e < conv_cube_pad(re); e += NT) cube[e] = 0;
-    if constexpr (FS) {
-        if (tid < LDWK) wl[WL_TILE - LDWK + tid] = 0;   // tap 171 (columns 10..15 of the tile: see conv_pool_own)
-    } else if constexpr (!PACKED) {
-        // zeros the filter scatter below does not overwrite: the second tile (filters 20..31) and tap 171 of the first
-        for (int e = WL_TILE - LDWK + tid; e < WL_LEN; e += NT) wl[e] = 0;
-    }
-    FB_TICK(12);
-    if (tid < no) lab[tid] = lab_g;   // the first use of a loaded value: after the zeroing, which needs none
-#pragma unroll
-    for (int u = 0; u < NW2; u++)
-        if (u * NT + tid < H * no) w2s[u * NT + tid] = w2r[u];
-    FB_TICK(13);
-#pragma unroll
-    for (int u = 0; u < NCREG; u++) {
-        const int e = u * NT + tid;
-        if (e < d.cube) cube[e] = creg[u];
-    }
-    FB_TICK(14);
-    if constexpr (PACKED) {
-#pragma unroll
-        for (int u = 0; u < NWREG; u++) {
-            const int e = u * NT + tid;
-            if (e < WP_LEN) wl[e] = (wok >> u & 1) ? wreg[u] : T(0);
-        }
-        FB_TICK(15);
-    } else {
-        __syncthreads();
-        FB_TICK(15);
-#pragma unroll
-        for (int u = 0; u < NWREG; u++) {
-            const int e = u * NT + tid;
-            if (e < NFO * K) {
-                const int f = e / K, k = e - f * K;   // FS: column f of the one tile holds filter fown + f
-                wl[wl_index(f, FLIP ? K - 1 - k : k)] = wreg[u];
-            }
-        }
-    }
-    __syncthreads();
-    FB_TICK(1);
-#if CCNN_STOP_PHASE == 1
-    return;
-#endif
-    if constexpr (FS) {
-        conv_pool_own<T>(cube, wl, re, bias0, fown, NFO, lane, wave, NW, [&](int f, int m, T v, int bt) {
-            pl[f * mre + m] = v;
-            px[f * mre + m] = bt;
-        });
-    } else if constexpr (PACKED) {
-        // one chain per wave: the position tiles of filters 0..15, then the packed tile's chains
-        for (int job = wave; job < conv_chains(re); job += NW) {
-            conv_pool_chain<T>(cube, wl, re, job, bias0, biasx, lane, [&](int f, int m, T v, int bt) {
-                pl[f * mre + m] = v;
-                px[f * mre + m] = bt;
-            });
-        }
-    } else {
-        conv_pool_tiles<T>(cube, 0, 1, wl, re, bias0, biasx, lane, wave, [&](int, int f, int m, T v, int bt) {
-            pl[f * mre + m] = v;
-            px[f * mre + m] = bt;
-        }, NW, NW > 4);
-    }
-    __syncthreads();
-    FB_TICK(2);
-#if CCNN_STOP_PHASE == 2
-    return;
-#endif
-    if constexpr (FS) {
-        const int o0 = half * (pout / 2);   // F is even: a half is ten whole filters
-        for (int o = tid; o < pout / 2; o += NT) pool_g[row * pout + o0 + o] = pl[o0 + o];
-    } else if (lead) {
-        for (int o = tid; o < pout; o += NT) pool_g[row * pout + o] = pl[o];
-    }
-
-    // ---- FC1 forward: z1[n] = sum_p pool[p] W1[n + 100 p] ---------------------------
-    // 16-byte vectors along n; QL lanes per W1 row (25 or 50 of them active), G row groups.
+    // The two walks over W1 (FC1 forward, delta at the pooled features): 16-byte vectors along n; QL
+    // lanes per W1 row (25 or 50 of them active), G row groups.
     typedef typename Vec16<T>::type V;
     constexpr int VW = Vec16<T>::W;
     constexpr int NQ = H / VW;
@@ -456,9 +385,125 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
 #pragma unroll
         for (int u = 0; u < UF; u++) w[u] = W1v[next_row() * NQ + qc];
     };
+    // The first round of W1 rows (UF per thread: at 103 bands a half's 210 rows are ONE round) depends
+    // on nothing computed here: it is fetched now, behind the cube and the filters, arrives under the
+    // staging and the conv phase, and stays in registers for BOTH walks where they cover the same rows
+    // in the same order (always, except with two workgroups per sample that both run the whole forward
+    // pass).  Only where a workgroup has a CU's registers to itself; every barrier from here to the
+    // backward walk orders LDS only, so that none of them waits for these loads.
+    constexpr bool PREW = WPE == 2 && CCNN_FB_PREW;
+    constexpr bool SAME_WALK = FS || SPLIT == 1;
+    static_assert(!PREW || UFF == UF, "the prefetched round serves both walks");
+    const unsigned p_start = p_run;
+    V wk[UF];
+    // 16-byte loads go through the CU's address path at 64 B/clk: eight waves' rounds are 0.9 us of it,
+    // and a wave that cannot issue does nothing else.  The waves with a conv job (one per position
+    // tile) fetch now, under the latency of the cube; the others at the start of the conv phase,
+    // which they would spend waiting.
+    const int conv_waves = FS ? conv_mtiles(re) : NW;
+    if constexpr (PREW)
+        if (wave < conv_waves) w1_rows(wk);
+    auto sync = [&]() {
+        if constexpr (PREW) lds_barrier();
+        else __syncthreads();
+    };
+    FB_TICK(11);
+    for (int e = d.cube + tid; e < conv_cube_pad(re); e += NT) cube[e] = 0;
+    if constexpr (FS) {
+        if (tid < LDWK) wl[WL_TILE - LDWK + tid] = 0;   // tap 171 (columns 10..15 of the tile: see conv_pool_own)
+    } else if constexpr (!PACKED) {
+        // zeros the filter scatter below does not overwrite: the second tile (filters 20..31) and tap 171 of the first
+        for (int e = WL_TILE - LDWK + tid; e < WL_LEN; e += NT) wl[e] = 0;
+    }
+    FB_TICK(12);
+    if (tid < no) lab[tid] = lab_g;   // the first use of a loaded value: after the zeroing, which needs none
+#pragma unroll
+    for (int u = 0; u < NW2; u++)
+        if (u * NT + tid < H * no) w2s[u * NT + tid] = w2r[u];
+    FB_TICK(13);
+#pragma unroll
+    for (int u = 0; u < NCREG; u++) {
+        const int e = u * NT + tid;
+        if (e < d.cube) cube[e] = creg[u];
+    }
+    FB_TICK(14);
+    if constexpr (PACKED) {
+#pragma unroll
+        for (int u = 0; u < NWREG; u++) {
+            const int e = u * NT + tid;
+            if (e < WP_LEN) wl[e] = (wok >> u & 1) ? wreg[u] : T(0);
+        }
+        FB_TICK(15);
+    } else {
+        sync();
+        FB_TICK(15);
+#pragma unroll
+        for (int u = 0; u < NWREG; u++) {
+            const int e = u * NT + tid;
+            if (e < NFO * K) {
+                const int f = e / K, k = e - f * K;   // FS: column f of the one tile holds filter fown + f
+                wl[wl_index(f, FLIP ? K - 1 - k : k)] = wreg[u];
+            }
+        }
+    }
+    sync();
+    FB_TICK(1);
+#if CCNN_STOP_PHASE == 1
+    return;
+#endif
+    if constexpr (PREW)
+        if (wave >= conv_waves) w1_rows(wk);
+    if constexpr (FS) {
+        conv_pool_own<T>(cube, wl, re, bias0, fown, NFO, lane, wave, NW, [&](int f, int m, T v, int bt) {
+            pl[f * mre + m] = v;
+            px[f * mre + m] = bt;
+        });
+    } else if constexpr (PACKED) {
+        // one chain per wave: the position tiles of filters 0..15, then the packed tile's chains
+        for (int job = wave; job < conv_chains(re); job += NW) {
+            conv_pool_chain<T>(cube, wl, re, job, bias0, biasx, lane, [&](int f, int m, T v, int bt) {
+                pl[f * mre + m] = v;
+                px[f * mre + m] = bt;
+            });
+        }
+    } else {
+        conv_pool_tiles<T>(cube, 0, 1, wl, re, bias0, biasx, lane, wave, [&](int, int f, int m, T v, int bt) {
+            pl[f * mre + m] = v;
+            px[f * mre + m] = bt;
+        }, NW, NW > 4);
+    }
+    sync();
+    FB_TICK(2);
+#if CCNN_STOP_PHASE == 2
+    return;
+#endif
+    if constexpr (FS) {
+        const int o0 = half * (pout / 2);   // F is even: a half is ten whole filters
+        for (int o = tid; o < pout / 2; o += NT) pool_g[row * pout + o0 + o] = pl[o0 + o];
+    } else if (lead) {
+        for (int o = tid; o < pout; o += NT) pool_g[row * pout + o] = pl[o];
+    }
+
+    // ---- FC1 forward: z1[n] = sum_p pool[p] W1[n + 100 p] ---------------------------
     {
         V acc = {};
-        for (int pb = 0; pb < (int)wlen; pb += G * UFF) {
+        p_run = p_start;
+        auto fc1_round = [&](int pb, const V(&w)[UFF], const unsigned(&prow)[UFF]) {
+#pragma unroll
+            for (int u = 0; u < UFF; u++) {
+                const T x = (qv && pb + u * G + g < (int)wlen) ? pl[prow[u]] : T(0);
+                acc += w[u] * x;
+            }
+        };
+        int pb0 = 0;
+        if constexpr (PREW) {
+            unsigned prow[UFF];
+#pragma unroll
+            for (int u = 0; u < UFF; u++) prow[u] = next_row();
+            fc1_round(0, wk, prow);
+            pb0 = G * UFF;
+        }
+        for (int pb = pb0; pb < (int)wlen; pb += G * UFF) {
             V w[UFF];
             unsigned prow[UFF];
 #pragma unroll
@@ -466,15 +511,19 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
                 prow[u] = next_row();
                 w[u] = W1v[prow[u] * NQ + qc];
             }
-#pragma unroll
-            for (int u = 0; u < UFF; u++) {
-                const T x = (qv && pb + u * G + g < (int)wlen) ? pl[prow[u]] : T(0);
-                acc += w[u] * x;
-            }
+            fc1_round(pb, w, prow);
         }
         if (qv) reinterpret_cast<V *>(z1p + g * H)[q] = acc;
     }
-    __syncthreads();
+    // The backward walk (delta at the pooled features, below): this workgroup's rows of W1.
+    if (SPLIT == 2) {
+        wlen = (unsigned)(pout / 2);   // F is even: a half is ten whole filters
+        wbase = half * wlen;
+    }
+    const int wrot = rot % (int)wlen;
+    p_run = (unsigned)((g + wrot) % (int)wlen);
+    if constexpr (PREW && !SAME_WALK) w1_rows(wk);   // other rows than the forward walk's: fetched under the head
+    sync();
     FB_TICK(3);
 #if CCNN_STOP_PHASE == 3
     return;
@@ -494,7 +543,7 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
         a1s[tid] = a;
         if (lead) a1_g[row * H + tid] = a;
     }
-    __syncthreads();
+    sync();
 
     FB_TICK(4);
     // ---- output layer, softmax, loss, delta2, delta1 ---------------------------------
@@ -510,7 +559,7 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
         mid += __shfl_xor(mid, 1);
         if (o8 < no && j8 == 0) es[o8] = rexp(mid + b2v);
     }
-    __syncthreads();
+    sync();
     FB_TICK(5);
     if (tid < no) {
         const T p = es[tid] / tree_n(es, no);
@@ -522,7 +571,7 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
     }
     // the filters are dead: clear their region for the scattered deltas
     for (int e = tid; e < 2 * L.ldd; e += NT) wl[e] = 0;
-    __syncthreads();
+    sync();
     FB_TICK(6);
     if (tid < H) {
         // bp_fully_connect(out -> hidden), gcn_mbgd_fp64.cu:416-434: class-wide tree
@@ -533,7 +582,7 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
         d1s[tid] = dv;
         if (lead) d1_g[row * H + tid] = dv;
     }
-    __syncthreads();
+    sync();
     FB_TICK(7);
 #if CCNN_STOP_PHASE == 4
     return;
@@ -547,11 +596,6 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
         static_assert(UF == 16, "reduce_scatter16 handles 16 rows per round");
         const int ru = reduce_scatter_index<QL>(q);          // the row of the round this lane ends up owning
         const bool writer = (q & (QL / 16 - 1)) == 0;        // one lane per owned row stores it
-        if (SPLIT == 2) {
-            wlen = (unsigned)(pout / 2);   // F is even: a half is ten whole filters
-            wbase = half * wlen;
-        }
-        const int wrot = rot % (int)wlen;
         auto dpool_rows = [&](int pb, const V(&w)[UF]) {
             T part[UF];   // d1v is zero in the lanes past the row's end
 #pragma unroll
@@ -576,8 +620,16 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
                     delta[(f >> 4) * L.ldd + px[p] * LDWK + (f & 15)] = dv;
             }
         };
-        p_run = (unsigned)((g + wrot) % (int)wlen);
-        for (int pb = 0; pb < (int)wlen; pb += CCNN_FB_UFB * G * UF) {
+        int pb0 = 0;
+        if constexpr (PREW) {
+            if constexpr (SAME_WALK) {   // the forward walk's first round, still in registers
+#pragma unroll
+                for (int u = 0; u < UF; u++) next_row();
+            }
+            dpool_rows(0, wk);
+            pb0 = G * UF;
+        }
+        for (int pb = pb0; pb < (int)wlen; pb += CCNN_FB_UFB * G * UF) {
             V w[CCNN_FB_UFB][UF];   // rows of several rounds in flight before the first is reduced
 #pragma unroll
             for (int h = 0; h < CCNN_FB_UFB; h++) w1_rows(w[h]);
@@ -586,43 +638,44 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
         }
     }
     __syncthreads();
-    FB_TICK(8);
-#if CCNN_STOP_PHASE == 5
-    return;
-#endif
 
     // ---- conv gradient tile of this sample -------------------------------------------
     T *out = slab + row * (long)(F * K + F);
-    if (SPLIT == 2)
-        conv_bwd_tiles<T, NW, true>(cube, wl, L.ldd, L.ks, re, out, lane, wave, half * (F / 2), F / 2);
-    else
-        conv_bwd_tiles<T, NW>(cube, wl, L.ldd, L.ks, re, out, lane, wave);
-    FB_TICK(9);
-    // the loss (a log and an exp per class, then the ordered sum) is nobody's input: the last wave,
-    // which has the fewest tap tiles of the conv gradient, computes it here at the end, lane o the
-    // terms of class o (ps and lab are not reused by the phases in between)
-    if (lead && tid >= NT - 64) {
-        const int o = tid - (NT - 64);
-        T ta = 0, tb = 0;
-        int lb = 0;
-        if (o < no) {
-            lb = lab[o];
-            loss_terms(ps[o], lb, &ta, &tb);
-        }
-        const double loss = loss_sum_lanes(ta, tb, lb, no);
-        if (o == 0) loss_values[row] = loss;
-    }
-    if (tid < F / SPLIT) {
+    // Two small serial jobs that are nobody's input ride on the waves with the fewest tap tiles of the
+    // conv gradient, before their tile, instead of behind everybody's: the conv-bias path on the
+    // last wave but one, the loss (a log and an exp per class, then the ordered sum; lane o the terms
+    // of class o; ps and lab are not reused by the phases in between) on the last.
+    if (wave == NW - 2 && lane < F / SPLIT) {
         // bias path: at a winner the conv output equals the pooled value, so the
         // reference's second tanh' (gcn_mbgd_fp64.cu:487-488) needs only pl
-        const int f = tid + half * (F / 2);
+        const int f = lane + half * (F / 2);
         T mid1 = 0;
+#pragma unroll 4
         for (int m = 0; m < mre; m++) {
             const T pv = pl[f * mre + m];
             mid1 = mid1 + dp[f * mre + m] * (1 + pv) * (1 - pv);
         }
         out[F * K + f] = mid1 / re;
     }
+    if (lead && wave == NW - 1) {
+        T ta = 0, tb = 0;
+        int lb = 0;
+        if (lane < no) {
+            lb = lab[lane];
+            loss_terms(ps[lane], lb, &ta, &tb);
+        }
+        const double loss = loss_sum_lanes(ta, tb, lb, no);
+        if (lane == 0) loss_values[row] = loss;
+    }
+    FB_TICK(8);
+#if CCNN_STOP_PHASE == 5
+    return;
+#endif
+    if (SPLIT == 2)
+        conv_bwd_tiles<T, NW, true>(cube, wl, L.ldd, L.ks, re, out, lane, wave, half * (F / 2), F / 2);
+    else
+        conv_bwd_tiles<T, NW>(cube, wl, L.ldd, L.ks, re, out, lane, wave);
+    FB_TICK(9);
     FB_TICK(10);
 }
 
