@@ -57,6 +57,9 @@ __device__ unsigned long long g_fb_ticks[32];
 #ifndef CCNN_FB_PREW
 #define CCNN_FB_PREW 1   // the backward walk's first round of W1 rows is fetched before the head
 #endif
+#ifndef CCNN_FB_PREW2
+#define CCNN_FB_PREW2 1  // ... and a second round in fp32
+#endif
 #ifndef CCNN_STOP_PHASE
 #define CCNN_STOP_PHASE 0   // diagnostic builds only: end sample_fwd_bwd after phase N
 #endif
@@ -400,9 +403,19 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
     // and a wave that cannot issue does nothing else.  The waves with a conv job (one per position
     // tile) fetch now, under the latency of the cube; the others at the start of the conv phase,
     // which they would spend waiting.
+    // fp32 keeps a second round where the walk has one (from 128 bands with two workgroups per
+    // sample): 128 of a thread's 256 registers then hold W1.
+    constexpr bool PREW2 = PREW && SAME_WALK && sizeof(T) == 4 && CCNN_FB_PREW2;
+    V wk2[UF];
+    const bool two = PREW2 && (int)wlen > G * UF;
     const int conv_waves = FS ? conv_mtiles(re) : NW;
-    if constexpr (PREW)
-        if (wave < conv_waves) w1_rows(wk);
+    if constexpr (PREW) {
+        if (wave < conv_waves) {
+            w1_rows(wk);
+            if constexpr (PREW2)
+                if (two) w1_rows(wk2);
+        }
+    }
     auto sync = [&]() {
         if constexpr (PREW) lds_barrier();
         else __syncthreads();
@@ -451,8 +464,13 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
 #if CCNN_STOP_PHASE == 1
     return;
 #endif
-    if constexpr (PREW)
-        if (wave >= conv_waves) w1_rows(wk);
+    if constexpr (PREW) {
+        if (wave >= conv_waves) {
+            w1_rows(wk);
+            if constexpr (PREW2)
+                if (two) w1_rows(wk2);
+        }
+    }
     if constexpr (FS) {
         conv_pool_own<T>(cube, wl, re, bias0, fown, NFO, lane, wave, NW, [&](int f, int m, T v, int bt) {
             pl[f * mre + m] = v;
@@ -502,6 +520,14 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
             for (int u = 0; u < UFF; u++) prow[u] = next_row();
             fc1_round(0, wk, prow);
             pb0 = G * UFF;
+            if constexpr (PREW2) {
+                if (two) {
+#pragma unroll
+                    for (int u = 0; u < UFF; u++) prow[u] = next_row();
+                    fc1_round(pb0, wk2, prow);
+                    pb0 += G * UFF;
+                }
+            }
         }
         for (int pb = pb0; pb < (int)wlen; pb += G * UFF) {
             V w[UFF];
@@ -628,6 +654,14 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
             }
             dpool_rows(0, wk);
             pb0 = G * UF;
+            if constexpr (PREW2) {
+                if (two) {
+#pragma unroll
+                    for (int u = 0; u < UF; u++) next_row();
+                    dpool_rows(pb0, wk2);
+                    pb0 += G * UF;
+                }
+            }
         }
         for (int pb = pb0; pb < (int)wlen; pb += CCNN_FB_UFB * G * UF) {
             V w[CCNN_FB_UFB][UF];   // rows of several rounds in flight before the first is reduced

@@ -1,0 +1,84 @@
+// Probe: what a launch of sample_fwd_bwd's shape costs when the kernel does (almost) nothing -
+// 256 workgroups x 512 threads, 60 KB of dynamic LDS, a register allocation of 240 per lane -
+// by the dispatch-attached events bench.py uses, alone and behind a second small kernel as in a
+// training step.  The difference between a kernel's event time and its in-kernel stamps is this.
+//   hipcc --offload-arch=gfx950 -O3 launch_floor.hip -o launch_floor
+#include <hip/hip_ext.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+
+#define CK(x)                                                                          \
+    do {                                                                               \
+        hipError_t e_ = (x);                                                           \
+        if (e_ != hipSuccess) {                                                        \
+            fprintf(stderr, "%s:%d: %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); \
+            return 1;                                                                  \
+        }                                                                              \
+    } while (0)
+
+template <int NREG>
+__global__ __launch_bounds__(512, 2) void shaped(float *out, int never)
+{
+    extern __shared__ float lds[];
+    float r[NREG];
+#pragma unroll
+    for (int i = 0; i < NREG; i++) r[i] = out[(threadIdx.x + i) & 1023];   // keeps NREG registers live
+    lds[threadIdx.x] = r[0];
+    __syncthreads();
+    float s = lds[(threadIdx.x + 1) & 511];
+    if (never) {
+#pragma unroll
+        for (int i = 0; i < NREG; i++) s += r[i] * r[(i + 7) % NREG];
+    }
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(512) void small(float *out) { out[blockIdx.x * 512 + threadIdx.x] += 1.0f; }
+
+int main()
+{
+    float *buf;
+    CK(hipMalloc(&buf, sizeof(float) * 512 * 512));
+    CK(hipMemset(buf, 0, sizeof(float) * 512 * 512));
+    hipEvent_t e0, e1, f0, f1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    CK(hipEventCreate(&f0));
+    CK(hipEventCreate(&f1));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(shaped<200>), hipFuncAttributeMaxDynamicSharedMemorySize, 61440));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(shaped<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 61440));
+    for (int big = 0; big < 2; big++) {
+        double a = 0, b = 0;
+        const int n = 200;
+        for (int i = 0; i < n + 20; i++) {
+            if (big) hipExtLaunchKernelGGL(shaped<200>, dim3(256), dim3(512), 61440, 0, e0, e1, 0, buf, 0);
+            else hipExtLaunchKernelGGL(shaped<8>, dim3(256), dim3(512), 61440, 0, e0, e1, 0, buf, 0);
+            hipExtLaunchKernelGGL(small, dim3(105), dim3(512), 0, 0, f0, f1, 0, buf);
+            CK(hipEventSynchronize(f1));
+            float ms0, ms1;
+            CK(hipEventElapsedTime(&ms0, e0, e1));
+            CK(hipEventElapsedTime(&ms1, f0, f1));
+            if (i >= 20) {
+                a += ms0;
+                b += ms1;
+            }
+        }
+        printf("%s registers: shaped kernel %.2f us, the small kernel behind it %.2f us (dispatch events)\n", big ? "~200" : "few", a / n * 1e3,
+               b / n * 1e3);
+    }
+    // back to back, wall clock per pair
+    hipEvent_t w0, w1;
+    CK(hipEventCreate(&w0));
+    CK(hipEventCreate(&w1));
+    CK(hipEventRecord(w0));
+    for (int i = 0; i < 2000; i++) {
+        hipLaunchKernelGGL(shaped<200>, dim3(256), dim3(512), 61440, 0, buf, 0);
+        hipLaunchKernelGGL(small, dim3(105), dim3(512), 0, 0, buf);
+    }
+    CK(hipEventRecord(w1));
+    CK(hipEventSynchronize(w1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, w0, w1));
+    printf("2000 pairs back to back: %.2f us per pair\n", ms / 2000 * 1e3);
+    return 0;
+}
