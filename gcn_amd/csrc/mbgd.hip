@@ -44,8 +44,15 @@ __device__ unsigned long long g_fb_ticks[32];
     do {                                                                       \
         if (blockIdx.x == 5 && threadIdx.x == 0) g_fb_ticks[k] = wall_clock64(); \
     } while (0)
+// ... and every workgroup its first instruction and the end of each of its waves ([block][0], [block][1 + wave])
+__device__ unsigned long long g_fb_wg[1024][9];
+#define FB_WG(slot)                                                                                      \
+    do {                                                                                                 \
+        if (blockIdx.x < 1024 && (threadIdx.x & 63) == 0) g_fb_wg[blockIdx.x][slot] = wall_clock64();    \
+    } while (0)
 #else
 #define FB_TICK(k) do { } while (0)
+#define FB_WG(slot) do { } while (0)
 #endif
 
 #ifndef CCNN_FB_UFF
@@ -288,6 +295,7 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
     if (SPLIT == 2 && row >= d_rows) return;   // the grid is rounded up to whole groups of 8 samples
     const bool lead = half == 0;               // the workgroup that stores the sample's shared outputs
     FB_TICK(0);
+    if (tid == 0) FB_WG(0);
     int *lab = reinterpret_cast<int *>(smem + L.lab_off);
     // the labels are needed deep in the dependent chain: fetch them with the first loads
     const int lab_g = onehot[(first + row) * no + min(tid, no - 1)];
@@ -675,21 +683,28 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
 
     // ---- conv gradient tile of this sample -------------------------------------------
     T *out = slab + row * (long)(F * K + F);
-    // Two small serial jobs that are nobody's input ride on the waves with the fewest tap tiles of the
-    // conv gradient, before their tile, instead of behind everybody's: the conv-bias path on the
-    // last wave but one, the loss (a log and an exp per class, then the ordered sum; lane o the terms
-    // of class o; ps and lab are not reused by the phases in between) on the last.
-    if (wave == NW - 2 && lane < F / SPLIT) {
+    // Two small serial jobs that are nobody's input ride on waves with one tap tile of the conv
+    // gradient, before their tile, instead of behind everybody's: the loss (a log and an exp per class,
+    // then the ordered sum; lane o the terms of class o; ps and lab are not reused by the phases in
+    // between) on the last wave, the conv-bias path on the wave that shares its SIMD (with eight waves
+    // and eleven tap tiles the other three SIMDs each hold a wave with two tiles).
+    constexpr int BIAS_WAVE = NW >= 8 ? NW - 1 - 4 : NW - 2;
+    if (wave == BIAS_WAVE) {
         // bias path: at a winner the conv output equals the pooled value, so the
-        // reference's second tanh' (gcn_mbgd_fp64.cu:487-488) needs only pl
-        const int f = lane + half * (F / 2);
-        T mid1 = 0;
-#pragma unroll 4
-        for (int m = 0; m < mre; m++) {
+        // reference's second tanh' (gcn_mbgd_fp64.cu:487-488) needs only pl.  LPF lanes per
+        // filter take every LPF-th pooled position; the first of them adds their sums in lane order.
+        constexpr int NF = F / SPLIT, LPF = 64 / NF;
+        const int fl = min(lane / LPF, NF - 1), j = lane - (lane / LPF) * LPF;
+        const int f = fl + half * (F / 2);
+        T part = 0;
+        for (int m = j; m < mre; m += LPF) {
             const T pv = pl[f * mre + m];
-            mid1 = mid1 + dp[f * mre + m] * (1 + pv) * (1 - pv);
+            part = part + dp[f * mre + m] * (1 + pv) * (1 - pv);
         }
-        out[F * K + f] = mid1 / re;
+        T mid1 = part;
+#pragma unroll
+        for (int k = 1; k < LPF; k++) mid1 = mid1 + __shfl_down(part, k);
+        if (j == 0 && lane < NF * LPF) out[F * K + f] = mid1 / re;
     }
     if (lead && wave == NW - 1) {
         T ta = 0, tb = 0;
@@ -711,6 +726,7 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
         conv_bwd_tiles<T, NW>(cube, wl, L.ldd, L.ks, re, out, lane, wave);
     FB_TICK(9);
     FB_TICK(10);
+    FB_WG(1 + wave);
 }
 
 // ---------------------------------------------------------------------------
@@ -2003,6 +2019,10 @@ extern "C" int ccnn_debug_split_ticks(unsigned long long *out)
 extern "C" int ccnn_debug_fb_ticks(unsigned long long *out)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fb_ticks), sizeof(unsigned long long) * 32);
+}
+extern "C" int ccnn_debug_fb_wg(unsigned long long *out)   // [1024][9]
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fb_wg), sizeof(unsigned long long) * 1024 * 9);
 }
 #endif
 

@@ -31,3 +31,18 @@ if os.environ.get("CCNN_FB_TIMING"):
     if t[11]:
         print("inside stage: loads issued +%dns, LDS zeroed +%dns, labels stored (first wait) +%dns, cube staged +%dns, barrier +%dns, filters scattered + barrier +%dns"
               % tuple((t[k] - t[0]) * 10 for k in (11, 12, 13, 14, 15, 1)))
+    if hasattr(lib, "ccnn_debug_fb_wg"):
+        w = (C.c_ulonglong * (1024 * 9))()
+        assert lib.ccnn_debug_fb_wg(w) == 0
+        a = np.array(w[:], dtype=np.int64).reshape(1024, 9)
+        grid = 16 * ((B + 7) // 8) if L.load().ccnn_mbgd_path(B, z, np.dtype(DT).itemsize) == 0 and B <= 128 else B
+        a = a[:min(grid, 1024)]
+        a = a[a[:, 0] > 0]
+        t0 = a[:, 0].min()
+        start = (a[:, 0] - t0) / 100.0
+        end = (a[:, 1:].max(axis=1) - t0) / 100.0
+        dur = end - start
+        wave_end = (a[:, 1:] - a[:, :1]) / 100.0
+        print(f"  {len(a)} workgroups: start median +{np.median(start):.2f} max +{start.max():.2f} us; own duration median {np.median(dur):.2f} "
+              f"min {dur.min():.2f} max {dur.max():.2f} us; last end +{end.max():.2f} us; waves' ends after their start (median over workgroups): "
+              + " ".join(f"{np.median(wave_end[:, k]):.2f}" for k in range(8)))
