@@ -50,9 +50,16 @@ __device__ unsigned long long g_fb_wg[1024][9];
     do {                                                                                                 \
         if (blockIdx.x < 1024 && (threadIdx.x & 63) == 0) g_fb_wg[blockIdx.x][slot] = wall_clock64();    \
     } while (0)
+// ... and every workgroup of grad_reduce its first instruction, the end of its sums and its end
+__device__ unsigned long long g_gr_wg[1024][3];
+#define GR_WG(slot)                                                                                   \
+    do {                                                                                              \
+        if (lb < 1024 && threadIdx.x == 0) g_gr_wg[lb][slot] = wall_clock64();                        \
+    } while (0)
 #else
 #define FB_TICK(k) do { } while (0)
 #define FB_WG(slot) do { } while (0)
+#define GR_WG(slot) do { } while (0)
 #endif
 
 #ifndef CCNN_FB_UFF
@@ -456,7 +463,7 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
         }
         FB_TICK(15);
     } else {
-        sync();
+        if constexpr (!FS) sync();   // FS: the zeroed row (tap 171) and the scattered taps are disjoint
         FB_TICK(15);
 #pragma unroll
         for (int u = 0; u < NWREG; u++) {
@@ -733,18 +740,19 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
 // Batch sums of the per-sample gradients, written in the flat parameter layout
 // (update_params_row/col, gcn_mbgd_fp64.cu:513-517, 546-550).  With an UpdateRule
 // the update is applied in the same pass instead of storing the gradient.
-//   blocks [0, nb_w1)  dW1[n + 100 p] = sum_b pool[b][p] d1[b][n]: one 16-wide p tile
-//                      per block, one neuron tile per wave (7 of the 8), K = batch (MFMA)
+//   blocks [0, nb_w1)  one 16 x 16 tile per block, K = batch (MFMA) split over the eight waves:
+//                      dW1[n + 100 p] = sum_b pool[b][p] d1[b][n] (p tile, neuron tile), then the 7
+//                      tiles of dW2[o + 13 n] = sum_b a1[b][n] d2[b][o] (neuron tile x classes)
 //   then column sums, 64 columns x 8 row groups per block, groups added in order:
 //     nb_w0 blocks     dW0 | db0 = sum_b slab[b][.]
-//     nb_w2 blocks     dW2[o + 13 n] = sum_b a1[b][n] d2[b][o]
 //     2 blocks         db1 = sum_b d1        1 block   db2 = sum_b d2
 #ifndef CCNN_FB_THREADS
 #define CCNN_FB_THREADS 512
 #endif
 constexpr int FB_THREADS = CCNN_FB_THREADS;   // threads per sample_fwd_bwd workgroup
 constexpr int GR_THREADS = 512;
-constexpr int GR_TILE_VALUES = 7 * 64 * 4;   // values a dW1 workgroup produces (16 x 112 tile)
+constexpr int GR_NT = (H + 15) / 16;         // neuron tiles of dW1
+constexpr int GR_TILE_VALUES = 256;          // values a dW1 workgroup produces (one 16 x 16 tile)
 
 template <typename T>
 struct UpdateRule {
@@ -788,14 +796,25 @@ __device__ __forceinline__ T colsum8(int B, int rg, int c, T *red, Term term)
     return tot;
 }
 
-// Batch sums of the per-sample factors, one output element per thread (four in the dW1 tiles),
-// then either stored / applied directly (one GPU) or first summed over the ranks: with
+// Batch sums of the per-sample factors, one output element per thread, then either stored /
+// applied directly (one GPU) or first summed over the ranks: with
 // xc.world > 0 a workgroup writes its outputs into its slot of every peer's exchange buffer,
 // raises its flag there, waits for the same workgroup of every rank and adds the world
 // contributions in rank order before `upd` sees them (comm.h).  No grid-wide barrier: a
 // workgroup only depends on its namesakes on the other ranks.
 // Batches of more than 256 samples take grad_reduce_big below instead.
-template <typename T, int KF, int NO>
+// dW1: a workgroup per 16 x 16 tile (p tile blk / 7, neuron tile blk mod 7) whose eight waves each
+// take an eighth of the batch - 4 k-steps of a batch of 128: eight loads per lane, all in flight, and
+// four matrix instructions - and meet in LDS, where the first 256 threads add the eight partial
+// tiles in wave order.  (One workgroup per p tile with a wave per neuron tile and the whole batch
+// per wave - 64 loads per lane, 32 dependent matrix instructions, two waves per SIMD - took 3.0 +
+// 0.7 us per workgroup where the column sums of the same launch take 1.3 + 0.3: it WAS the launch.)
+// dW2 is a matrix product too (it was column sums of a1 x d2 products, two loads per row: once the
+// tiles no longer kept the kernel's register count up, the compiler fetched those rows a few at a
+// time - 1.9 -> 4.8 us).  The kernel keeps to 64 registers, four workgroups per CU: ranks that share
+// one GPU (tests, rehearsals) wait for each other inside it, and a rank whose workgroups found no
+// room beside the others' would never answer.
+template <typename T, int NO>
 __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int off_w1, int off_b1,
                                                           int off_w2, int off_b2,
                                                           const T *__restrict__ pool,
@@ -803,51 +822,63 @@ __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int o
                                                           const T *__restrict__ d1,
                                                           const T *__restrict__ d2,
                                                           const T *__restrict__ slab, int slab_rows, int nb_w1,
-                                                          int nb_w0, int nb_w2, T *__restrict__ grad,
+                                                          int nb_w0, T *__restrict__ grad,
                                                           UpdateRule<T> upd, CommDev xc,
                                                           unsigned xstep)
 {
-    __shared__ T red[8 * 64];
+    __shared__ T red[8 * 256];
     const int tid = threadIdx.x;
     const int no = NO ? NO : (off_b2 - off_w2) / H;   // classes: W2 is [100 x classes]; NO as in sample_fwd_bwd
-    int blk = blockIdx.x;
+    // the column-sum workgroups are dispatched first (their rounds of loads are the longer chain),
+    // the dW1 tiles after them; lb is the workgroup's number in the order of the list above
+    const int nsmall = (int)gridDim.x - nb_w1;
+    const int lb = (int)blockIdx.x < nsmall ? nb_w1 + (int)blockIdx.x : (int)blockIdx.x - nsmall;
+    int blk = lb;
+    GR_WG(0);
     int ok[4] = {-1, -1, -1, -1};   // parameter index of this thread's outputs (-1: none)
     T og[4] = {0, 0, 0, 0};         // and their batch sums
     if (blk < nb_w1) {
         const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        if (wave < 7) {
-            const int col = lane & 15, kq = lane >> 4;
-            const int p0 = blk * 16, n0 = wave * 16;
-            const bool pv = p0 + col < pout, nv = n0 + col < H;
-            const T *ap = pool + min(p0 + col, pout - 1);   // clamped: loads stay in bounds, masked below
-            const T *bp = d1 + min(n0 + col, H - 1);
-            typename Mma<T>::acc_t acc = {0, 0, 0, 0};
-            const int ks = (B + 3) >> 2;
-            // KF k-steps of operands in flight: 32 takes a batch of 128 in one memory round trip
-            // (16 -> 32 in fp32: step 24.6 -> 23.3 us).  The fp64 kernel with 16 keeps within 128
-            // registers, so that two workgroups fit a CU: the host picks that form only for ranks
-            // that share one GPU, which wait for each other inside this kernel and must all be
-            // resident at once.
-            for (int s = 0; s < ks; s += KF) {
-                T a[KF], w[KF];
+        const int col = lane & 15, kq = lane >> 4;
+        // rows x columns of the tile: 16 pooled features x 16 neurons of dW1 (operands pool, d1), or, in
+        // the last GR_NT tile workgroups, 16 neurons x the classes of dW2 (operands a1, d2)
+        const int pt = blk / GR_NT, nt = blk - pt * GR_NT;
+        const bool w2 = pt == nb_w1 / GR_NT - 1;
+        const int nrow = w2 ? H : pout, ncol = w2 ? no : H;   // = the operands' row strides
+        const int p0 = (w2 ? nt : pt) * 16, n0 = w2 ? 0 : nt * 16;
+        const int obase = w2 ? off_w2 : off_w1;
+        const bool pv = p0 + col < nrow, nv = n0 + col < ncol;
+        const T *ap = (w2 ? a1 : pool) + min(p0 + col, nrow - 1);   // clamped: loads stay in bounds, masked below
+        const T *bp = (w2 ? d2 : d1) + min(n0 + col, ncol - 1);
+        typename Mma<T>::acc_t acc = {0, 0, 0, 0};
+        const int ks = (B + 3) >> 2, kpw = (ks + 7) >> 3;   // k-steps of four samples: all, per wave
+        const int s_lo = wave * kpw, s_hi = min(ks, s_lo + kpw);
+        constexpr int KW = 8;   // k-steps of operands in flight (a batch of up to 256 in one round)
+        for (int s = s_lo; s < s_hi; s += KW) {
+            T a[KW], w[KW];
 #pragma unroll
-                for (int u = 0; u < KF; u++) {
-                    const int b = min(4 * (s + u) + kq, B - 1);
-                    a[u] = ap[(long)b * pout];
-                    w[u] = bp[(long)b * H];
-                }
-#pragma unroll
-                for (int u = 0; u < KF; u++) {
-                    const bool bv = 4 * (s + u) + kq < B;
-                    acc = Mma<T>::mma((bv && pv) ? a[u] : T(0), (bv && nv) ? w[u] : T(0), acc);
-                }
+            for (int u = 0; u < KW; u++) {
+                const int b = min(4 * (s + u) + kq, B - 1);
+                a[u] = ap[(long)b * nrow];
+                w[u] = bp[(long)b * ncol];
             }
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int p = p0 + Mma<T>::row(lane, r);
-                ok[r] = (nv && p < pout) ? off_w1 + n0 + col + H * p : -1;
-                og[r] = acc[r];
+            for (int u = 0; u < KW; u++) {
+                const bool bv = s + u < s_hi && 4 * (s + u) + kq < B;
+                acc = Mma<T>::mma((bv && pv) ? a[u] : T(0), (bv && nv) ? w[u] : T(0), acc);
             }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[wave * 256 + r * 64 + lane] = acc[r];
+        __syncthreads();
+        if (tid < 256) {
+            T tot = 0;
+#pragma unroll
+            for (int w = 0; w < 8; w++) tot = tot + red[w * 256 + tid];
+            const int r = tid >> 6, l = tid & 63;   // accumulator register r of lane l
+            const int p = p0 + Mma<T>::row(l, r), n = n0 + (l & 15);
+            if (n < ncol && p < nrow) ok[0] = obase + n + ncol * p;   // dW1[n + 100 p], dW2[o + classes n]
+            og[0] = tot;
         }
     } else {
         blk -= nb_w1;
@@ -859,16 +890,8 @@ __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int o
                 ok[0] = k;
                 og[0] = tot;
             }
-        } else if (blk < nb_w0 + nb_w2) {
-            const int k = min((blk - nb_w0) * 64 + c, H * no - 1);   // k = o + classes * n
-            const int nn = k / no, o = k - nn * no;
-            const T tot = colsum8<T>(B, rg, c, red, [&](int b) { return a1[(long)b * H + nn] * d2[(long)b * no + o]; });
-            if (rg == 0 && (blk - nb_w0) * 64 + c < H * no) {
-                ok[0] = off_w2 + k;
-                og[0] = tot;
-            }
-        } else if (blk < nb_w0 + nb_w2 + 2) {
-            const int q = blk - nb_w0 - nb_w2;
+        } else if (blk < nb_w0 + 2) {
+            const int q = blk - nb_w0;
             const int n = min(q * 64 + c, H - 1);
             const T tot = colsum8<T>(B, rg, c, red, [&](int b) { return d1[(long)b * H + n]; });
             if (rg == 0 && q * 64 + c < H) {
@@ -884,21 +907,22 @@ __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int o
             }
         }
     }
+    GR_WG(1);
     int gave_up = 0;
     if (xc.world > 0) {
         // The outputs travel in launch geometry, not in parameter order (a dW1 workgroup's slot
-        // region holds four values per thread, the others one value per lane of their first wave),
+        // region holds one value per thread of its first four waves, the others one per lane of their first wave),
         // each 32-bit half of a value in its own sequence-tagged word (comm.h): a thread trades
         // with its namesakes on the other ranks without any fence, flag or barrier.  (A
         // system-scope fence here would have to write back the megabytes of dirty L2 lines the
         // per-sample kernel has just left behind: measured +14 us per step.)
         constexpr int WPV = sizeof(T) / 4;   // tagged words per value
         const int par = xstep & 1;
-        const bool tile = (int)blockIdx.x < nb_w1;
-        const bool sender = tile ? tid < 7 * 64 : tid < 64;
-        const int nv = tile ? 4 : 1;         // values this thread trades
-        const long word0 = (tile ? (long)blockIdx.x * GR_TILE_VALUES + 4 * tid
-                                 : (long)nb_w1 * GR_TILE_VALUES + (long)(blockIdx.x - nb_w1) * 64 + tid) * WPV;
+        const bool tile = lb < nb_w1;
+        const bool sender = tile ? tid < GR_TILE_VALUES : tid < 64;
+        const int nv = 1;                    // values this thread trades
+        const long word0 = (tile ? (long)lb * GR_TILE_VALUES + tid
+                                 : (long)nb_w1 * GR_TILE_VALUES + (long)(lb - nb_w1) * 64 + tid) * WPV;
         if (sender) {
             unsigned bits[4 * WPV];
 #pragma unroll
@@ -933,7 +957,7 @@ __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int o
             // of a vector per rank over the links instead of world-1 vectors, for a second hop.  A
             // workgroup's slots [par][r] are used in one direction only per call (contributions at the
             // owner, the total elsewhere), so both hops share the buffers and the sequence number.
-            const int owner = xc.via_owner ? (int)(blockIdx.x % xc.world) : -1;
+            const int owner = xc.via_owner ? lb % xc.world : -1;
             unsigned in[4 * WPV];
             if (owner >= 0 && owner != xc.rank) {
                 send(owner, xc.rank, bits);
@@ -987,6 +1011,7 @@ __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int o
 #pragma unroll
     for (int j = 0; j < 4; j++)
         if (ok[j] >= 0) upd.apply(grad, ok[j], og[j]);
+    GR_WG(2);
 }
 
 
@@ -1834,10 +1859,9 @@ template <typename T>
 int launch_grad_reduce(int B, const ccnn_dims_t &d, const MbgdWs<T> &w, int slab_rows, T *grad, UpdateRule<T> upd,
                        ccnn_comm *cm, hipStream_t st)
 {
-    const int nb_w1 = (d.pout + 15) / 16;
+    const int nb_w1 = GR_NT * ((d.pout + 15) / 16 + 1);   // tiles of dW1, then of dW2
     const int nb_w0 = (F * K + F + 63) / 64;
-    const int nb_w2 = (H * d.n_classes + 63) / 64;
-    const int nblocks = nb_w1 + nb_w0 + nb_w2 + 3;
+    const int nblocks = nb_w1 + nb_w0 + 3;
     CommDev xc = {};
     unsigned xstep = 0;
     if (cm) {
@@ -1860,14 +1884,11 @@ int launch_grad_reduce(int B, const ccnn_dims_t &d, const MbgdWs<T> &w, int slab
         xc = cm->dev;
         xstep = cm->next_step();
     }
-    const bool narrow = sizeof(T) == 8 && cm && cm->shared_device;
     const bool c13 = d.n_classes == CCNN_CLASSES;
-    launch("grad_reduce",
-           narrow ? (c13 ? grad_reduce<T, 16, CCNN_CLASSES> : grad_reduce<T, 16, 0>)
-                  : (c13 ? grad_reduce<T, 32, CCNN_CLASSES> : grad_reduce<T, 32, 0>),
+    launch("grad_reduce", c13 ? grad_reduce<T, CCNN_CLASSES> : grad_reduce<T, 0>,
            dim3(nblocks), dim3(GR_THREADS), 0, st,
            B, d.pout, d.off_w1, d.off_b1, d.off_w2, d.off_b2, w.pool, w.a1, w.d1, w.d2, w.slab, slab_rows, nb_w1, nb_w0,
-           nb_w2, grad, upd, xc, xstep);
+           grad, upd, xc, xstep);
     CCNN_LAUNCH_CHECK();
     return 0;
 }
@@ -2019,6 +2040,10 @@ extern "C" int ccnn_debug_split_ticks(unsigned long long *out)
 extern "C" int ccnn_debug_fb_ticks(unsigned long long *out)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fb_ticks), sizeof(unsigned long long) * 32);
+}
+extern "C" int ccnn_debug_gr_wg(unsigned long long *out)   // [1024][3]
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gr_wg), sizeof(unsigned long long) * 1024 * 3);
 }
 extern "C" int ccnn_debug_fb_wg(unsigned long long *out)   // [1024][9]
 {

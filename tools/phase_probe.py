@@ -46,3 +46,20 @@ if os.environ.get("CCNN_FB_TIMING"):
         print(f"  {len(a)} workgroups: start median +{np.median(start):.2f} max +{start.max():.2f} us; own duration median {np.median(dur):.2f} "
               f"min {dur.min():.2f} max {dur.max():.2f} us; last end +{end.max():.2f} us; waves' ends after their start (median over workgroups): "
               + " ".join(f"{np.median(wave_end[:, k]):.2f}" for k in range(8)))
+    if hasattr(lib, "ccnn_debug_gr_wg"):
+        w2 = (C.c_ulonglong * (1024 * 3))()
+        assert lib.ccnn_debug_gr_wg(w2) == 0
+        r = np.array(w2[:], dtype=np.int64).reshape(1024, 3)
+        r = r[r[:, 0] > 0]
+        fb_t0, fb_end = a[:, 0].min(), a[:, 1:].max()
+        st, sm, en = (r[:, 0] - fb_t0) / 100.0, (r[:, 1] - fb_t0) / 100.0, (r[:, 2] - fb_t0) / 100.0
+        print(f"  grad_reduce, {len(r)} workgroups, us after the first start of sample_fwd_bwd (whose last wave ended at +{(fb_end - fb_t0) / 100.0:.2f}): "
+              f"first start +{st.min():.2f}, last start +{st.max():.2f}; sums done median +{np.median(sm):.2f} last +{sm.max():.2f}; "
+              f"last end +{en.max():.2f}; per workgroup: sums {np.median(sm - st):.2f} (max {(sm - st).max():.2f}), update {np.median(en - sm):.2f} (max {(en - sm).max():.2f})")
+        nb_w1 = 7 * ((d.pout + 15) // 16 + 1)
+        nb_w0 = (20 * 171 + 20 + 63) // 64
+        w3 = np.array(w2[:], dtype=np.int64).reshape(1024, 3)
+        for name, lo, hi in (("dW1 and dW2 tiles", 0, nb_w1), ("conv-gradient column sums", nb_w1, nb_w1 + nb_w0), ("db1, db2", nb_w1 + nb_w0, nb_w1 + nb_w0 + 3)):
+            k = w3[lo:hi]
+            print(f"    {name} ({hi - lo} workgroups): start +{(k[:, 0].min() - fb_t0) / 100.0:.2f}..+{(k[:, 0].max() - fb_t0) / 100.0:.2f}, sums {np.median(k[:, 1] - k[:, 0]) / 100.0:.2f} "
+                  f"(max {(k[:, 1] - k[:, 0]).max() / 100.0:.2f}), update {np.median(k[:, 2] - k[:, 1]) / 100.0:.2f} (max {(k[:, 2] - k[:, 1]).max() / 100.0:.2f}), last end +{(k[:, 2].max() - fb_t0) / 100.0:.2f}")

@@ -80,5 +80,21 @@ int main()
     float ms;
     CK(hipEventElapsedTime(&ms, w0, w1));
     printf("2000 pairs back to back: %.2f us per pair\n", ms / 2000 * 1e3);
+    // what the shape contributes: workgroups, threads, LDS of the first kernel; workgroups of the second
+    struct Shape { int g1, t1, lds, g2, t2; } shapes[] = {
+        {256, 512, 61440, 105, 512}, {256, 512, 0, 105, 512},  {256, 256, 61440, 105, 512}, {128, 512, 61440, 105, 512},
+        {256, 512, 61440, 105, 256}, {256, 512, 61440, 32, 512}, {256, 512, 61440, 256, 512}, {256, 64, 0, 32, 64}, {1, 64, 0, 1, 64}};
+    for (const Shape &sh : shapes) {
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(w0));
+        for (int i = 0; i < 2000; i++) {
+            hipLaunchKernelGGL(shaped<8>, dim3(sh.g1), dim3(sh.t1), sh.lds, 0, buf, 0);
+            hipLaunchKernelGGL(small, dim3(sh.g2), dim3(sh.t2), 0, 0, buf);
+        }
+        CK(hipEventRecord(w1));
+        CK(hipEventSynchronize(w1));
+        CK(hipEventElapsedTime(&ms, w0, w1));
+        printf("first %3d x %3d threads, %5d B of LDS; second %3d x %3d: %.2f us per pair\n", sh.g1, sh.t1, sh.lds, sh.g2, sh.t2, ms / 2000 * 1e3);
+    }
     return 0;
 }
