@@ -45,8 +45,6 @@ def kernel_work(d, z):
         "tile_fwd_bwd": ("mfma", 2 * conv + 2 * fc1 + 4.0 * 1300),
         # dW1 = pool^T d1, dW2 = a1^T d2
         "grad_reduce": ("mfma", fc1 + 2.0 * 1300),
-        "grad_reduce_big": ("mfma", fc1 + 2.0 * 1300),
-        "grad_reduce_split": ("mfma", fc1 + 2.0 * 1300),
         "conv_pool_fwd": ("mfma", conv),
         "fc_head_fwd": ("mfma", fc1 + 2.0 * 1300),
         # the batched training path: conv fwd | FC1 + FC2 fwd + delta1 | delta at the pooled features | conv gradient
@@ -125,7 +123,7 @@ def kernel_rows(rep, d, z, pixels, passes=None, world=1, es=4):
     return rows
 
 
-TRAIN_KERNELS = ("sample_fwd_bwd", "tile_fwd_bwd", "grad_reduce", "grad_reduce_big", "grad_reduce_split", "update_f32_kernel", "allreduce_apply", "conv_pool_fwd_train",
+TRAIN_KERNELS = ("sample_fwd_bwd", "tile_fwd_bwd", "grad_reduce", "update_f32_kernel", "allreduce_apply", "conv_pool_fwd_train",
                  "fc_head_fwd_train", "dpool_bwd", "conv_bwd_batch")
 STEP_PATHS = {0: "fused per-sample kernel", 1: "sample-tile kernel", 2: "batched layer kernels"}   # ccnn_mbgd_path
 

@@ -21,8 +21,8 @@
 // That is the step at the reference's batch sizes.  Batches of several hundred samples and more
 // take tile_fwd_bwd (tile.hip: a tile of samples per workgroup, FC1 as a matrix product that
 // reads W1 once per tile) or, where no tile fits the LDS, the layer kernels below
-// (conv_pool_fwd<TRAIN> + fc_head_fwd<TRAIN> of forward.hip, dpool_bwd, conv_bwd_batch), and
-// grad_reduce_big for the batch sums; step_path() chooses.
+// (conv_pool_fwd<TRAIN> + fc_head_fwd<TRAIN> of forward.hip, dpool_bwd, conv_bwd_batch); grad_reduce
+// sums the batch behind each of them; step_path() chooses.
 #include <unistd.h>
 
 #include <atomic>
@@ -802,7 +802,6 @@ __device__ __forceinline__ T colsum8(int B, int rg, int c, T *red, Term term)
 // raises its flag there, waits for the same workgroup of every rank and adds the world
 // contributions in rank order before `upd` sees them (comm.h).  No grid-wide barrier: a
 // workgroup only depends on its namesakes on the other ranks.
-// Batches of more than 256 samples take grad_reduce_big below instead.
 // dW1: a workgroup per 16 x 16 tile (p tile blk / 7, neuron tile blk mod 7) whose eight waves each
 // take an eighth of the batch - 4 k-steps of a batch of 128: eight loads per lane, all in flight, and
 // four matrix instructions - and meet in LDS, where the first 256 threads add the eight partial
@@ -853,7 +852,7 @@ __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int o
         typename Mma<T>::acc_t acc = {0, 0, 0, 0};
         const int ks = (B + 3) >> 2, kpw = (ks + 7) >> 3;   // k-steps of four samples: all, per wave
         const int s_lo = wave * kpw, s_hi = min(ks, s_lo + kpw);
-        constexpr int KW = 8;   // k-steps of operands in flight (a batch of up to 256 in one round)
+        constexpr int KW = 8;   // k-steps of operands in flight: a batch of up to 256 in one round (16: no faster at 1024 .. 4096)
         for (int s = s_lo; s < s_hi; s += KW) {
             T a[KW], w[KW];
 #pragma unroll
@@ -1021,7 +1020,7 @@ __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int o
 //   conv_pool_fwd<TRAIN> + fc_head_fwd<TRAIN>   forward, loss, delta2, delta1        (forward.hip)
 //   dpool_bwd        dpool = (delta1 W1^T)(1 + pool)(1 - pool): one [B x 100] x [100 x Pout] product
 //   conv_bwd_batch   bp_maxpooling scatter + conv gradient, accumulated over a workgroup's samples
-//   grad_reduce_big  dW1 = pool^T delta1, dW2, db1, db2, the column sums of conv_bwd_batch's partials, the update
+//   grad_reduce      dW1 = pool^T delta1, dW2, db1, db2, the column sums of conv_bwd_batch's partials, the update
 // W1 is read once per 16-row tile of the products instead of twice per sample.
 
 // dpool[b][p] = (sum_n W1[n + 100 p] d1[b][n]) (1 + pool[b][p]) (1 - pool[b][p])
@@ -1123,11 +1122,9 @@ template <typename T, int NBUF>
 __global__ __launch_bounds__(CB_THREADS) void conv_bwd_batch(const T *__restrict__ cubes, long first,
                                                              const T *__restrict__ dp, const T *__restrict__ pool,
                                                              const unsigned char *__restrict__ px, int B,
-                                                             int cube_elems, int re, int mre, T *__restrict__ part,
-                                                             unsigned *zero_ctr)
+                                                             int cube_elems, int re, int mre, T *__restrict__ part)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (zero_ctr && blockIdx.x == 0 && threadIdx.x < TRAIN_ZERO_INTS) zero_ctr[threadIdx.x] = 0;   // for the batch sums that follow
     const ConvBwdLds<T> L(re, mre);
     T *base = reinterpret_cast<T *>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1265,381 +1262,19 @@ __global__ __launch_bounds__(CB_THREADS) void conv_bwd_batch(const T *__restrict
     if (wave == 0 && lane < F) out[F * K + lane] = bsum / re;
 }
 
-// Batch sums for large batches in ONE pass (grad_reduce above gives a thread all B rows of its
-// output: a 2048-row sum would be 16 dependent rounds of loads).  Here the batch is split over the
-// waves of a workgroup instead and the partial sums meet in LDS:
-//   7 x nb_w1 workgroups   (nb_w1 = p tiles rounded up to a multiple of eight)
-//                          one 16 x 16 tile of dW1 = pool^T d1 each (p tile, neuron tile); wave w
-//                          multiplies rows [w bs, (w+1) bs) of the batch, the eight accumulators
-//                          are added in wave order
-//   nb_w0 workgroups       64 columns x 8 row groups of the conv-gradient partials (few rows)
-//   then 16 columns x 32 row groups: dW2[o + classes n] = sum_b a1[b][n] d2[b][o], db1, db2
-// Every output is final, so the update (or the store of the summed gradient) happens here.
-constexpr int GB_THREADS = 512;
-template <typename T, int NO>
-__global__ __launch_bounds__(GB_THREADS) void grad_reduce_big(int B, int pout, int off_w1, int off_b1, int off_w2,
-                                                              int off_b2, const T *__restrict__ pool,
-                                                              const T *__restrict__ a1, const T *__restrict__ d1,
-                                                              const T *__restrict__ d2, const T *__restrict__ slab,
-                                                              int slab_rows, int nb_w1, int nb_w0, int nb_w2,
-                                                              int nb_b1, T *__restrict__ grad, UpdateRule<T> upd)
-{
-    __shared__ T red[8 * 256];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int no = NO ? NO : (off_b2 - off_w2) / H;
-    int blk = blockIdx.x;
-    if (blk < 7 * nb_w1) {
-        // the seven neuron tiles of one p tile run on ONE XCD (workgroup b lands on XCD b mod 8), so a
-        // slice of pool is fetched from memory into one L2 instead of into seven
-        const int xcd = blk & 7, i = blk >> 3;
-        const int pt = 8 * (i / 7) + xcd, ntile = i % 7;
-        if (pt * 16 >= pout) return;   // the grid is rounded up to whole groups of eight p tiles
-        const int col = lane & 15, kq = lane >> 4;
-        const int p0 = pt * 16, n0 = ntile * 16;
-        const int bs = ((B + 7) / 8 + 3) & ~3;   // rows per wave: whole k-steps
-        const int b_lo = min(wave * bs, B), len = min(b_lo + bs, B) - b_lo;
-        const bool pv = p0 + col < pout, nv = n0 + col < H;
-        typename Mma<T>::acc_t acc = {0, 0, 0, 0};
-        if (len > 0) {
-            const T *ap = pool + (long)b_lo * pout + min(p0 + col, pout - 1);   // clamped: loads stay in bounds, masked below
-            const T *bp = d1 + (long)b_lo * H + min(n0 + col, H - 1);
-            const int ks = (len + 3) >> 2;
-            // k-steps of operands in flight.  Measured at B = 2048 (fp32): 16 -> 22.4 us, 32 -> 12.9 us,
-            // 64 -> 15.6 us for the launch: a round of loads costs about 5 us whatever its size (every
-            // load touches four rows of pool, 1.7 KB apart), and 64 clamps too many rows of small batches
-            constexpr int KF = sizeof(T) == 4 ? 32 : 16;
-            for (int s = 0; s < ks; s += KF) {
-                T a[KF], w[KF];
-#pragma unroll
-                for (int u = 0; u < KF; u++) {
-                    const int b = min(4 * (s + u) + kq, len - 1);
-                    a[u] = ap[(long)b * pout];
-                    w[u] = bp[(long)b * H];
-                }
-#pragma unroll
-                for (int u = 0; u < KF; u++) {
-                    const bool bv = 4 * (s + u) + kq < len;
-                    acc = Mma<T>::mma((bv && pv) ? a[u] : T(0), (bv && nv) ? w[u] : T(0), acc);
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r++) red[wave * 256 + r * 64 + lane] = acc[r];
-        __syncthreads();
-        if (tid < 256) {
-            const int r = tid >> 6, ln = tid & 63;
-            T tot = 0;
-#pragma unroll
-            for (int w = 0; w < 8; w++) tot = tot + red[w * 256 + tid];
-            const int p = p0 + Mma<T>::row(ln, r), n = n0 + (ln & 15);
-            if (p < pout && n < H) upd.apply(grad, off_w1 + n + H * p, tot);
-        }
-        return;
-    }
-    blk -= 7 * nb_w1;
-    if (blk < nb_w0) {
-        const int c = tid & 63, rg = tid >> 6;
-        const int k = min(blk * 64 + c, F * K + F - 1);
-        const T tot = colsum8<T>(slab_rows, rg, c, red, [&](int b) { return slab[(long)b * (F * K + F) + k]; });
-        if (rg == 0 && blk * 64 + c < F * K + F) upd.apply(grad, k, tot);   // partial layout = W0 | b0 = params[0..)
-        return;
-    }
-    blk -= nb_w0;
-    const int c = tid & 15, rg = tid >> 4;   // 16 columns x 32 row groups
-    auto colsum32 = [&](auto term) {
-        T acc = 0;
-        for (int b0 = rg; b0 < B; b0 += 32 * 16) {
-            T v[16];
-#pragma unroll
-            for (int u = 0; u < 16; u++) {
-                const int b = b0 + 32 * u;
-                const T x = term(min(b, B - 1));   // clamped load, masked value
-                v[u] = b < B ? x : T(0);
-            }
-#pragma unroll
-            for (int u = 0; u < 16; u++) acc = acc + v[u];
-        }
-        red[rg * 16 + c] = acc;
-        __syncthreads();
-        T tot = 0;
-        if (rg == 0) {
-#pragma unroll
-            for (int r = 0; r < 32; r++) tot = tot + red[r * 16 + c];
-        }
-        return tot;
-    };
-    if (blk < nb_w2) {
-        const int k = min(blk * 16 + c, H * no - 1);   // k = o + classes * n
-        const int nn = k / no, o = k - nn * no;
-        const T tot = colsum32([&](int b) { return a1[(long)b * H + nn] * d2[(long)b * no + o]; });
-        if (rg == 0 && blk * 16 + c < H * no) upd.apply(grad, off_w2 + k, tot);
-    } else if (blk < nb_w2 + nb_b1) {
-        const int q = blk - nb_w2;
-        const int n = min(q * 16 + c, H - 1);
-        const T tot = colsum32([&](int b) { return d1[(long)b * H + n]; });
-        if (rg == 0 && q * 16 + c < H) upd.apply(grad, off_b1 + n, tot);
-    } else {
-        const int o = min(c, no - 1);
-        const T tot = colsum32([&](int b) { return d2[(long)b * no + o]; });
-        if (rg == 0 && c < no) upd.apply(grad, off_b2 + o, tot);
-    }
-}
-
-// Batch sums for the largest batches, the batch split over WORKGROUPS as well (grad_reduce_big gives a
-// 16 x 16 tile of dW1 all rows of the batch: every operand value is fetched from L2 once per tile,
-// 64 bytes of a row at a time - 49 MB of L2 traffic for 4 MB of data at 2048 samples, and the launch
-// is bound by those requests).  Here a workgroup takes one 16-feature tile of pool and ALL hundred
-// neurons for one slice of the batch:
-//   npt x nsl workgroups   p tile pt, rows [sl bs, (sl + 1) bs): its rows of d1 are one contiguous run
-//                          of memory and come in with 16-byte loads, all issued before anything else
-//                          (one memory round trip), then go through LDS a chunk of GS_CH rows at a
-//                          time (double-buffered); wave w multiplies neuron tile w.  Slice sl runs on
-//                          XCD sl mod 8, so a slice of d1 is fetched into one L2.  The [16 x 112]
-//                          partial goes to memory write-through; the workgroup that arrives LAST at
-//                          the p tile's counter adds the nsl partials in slice order (the same order
-//                          whoever arrives last: bit-identical results) and applies the update.
-//   then the column sums exactly as in grad_reduce_big (conv-gradient partials, dW2, db1, db2).
-// No workgroup ever waits for another.  Hand-over inside the launch: the partials are stored with
-// agent-scope write-through stores and every wave waits for their acknowledgement before the
-// workgroup arrives (what a release fence does, minus the write-back of an L2 that holds nothing else
-// of this kernel's); the last arriver reads them past its caches.  The counters must be zero at
-// launch: the kernel that precedes this one in the step clears them, and the last arriver leaves
-// them at zero again.
-#ifndef CCNN_SPLIT_PROBE
-#define CCNN_SPLIT_PROBE 0
-#endif
-// Diagnostic builds only (-DCCNN_SPLIT_TIMING): thread 0 of every dW1 workgroup stamps the 100 MHz wall
-// clock at GS_TICK(k); ccnn_debug_split_ticks() returns the stamps of the last launch ([workgroup][8]).
-#ifdef CCNN_SPLIT_TIMING
-__device__ unsigned long long g_split_ticks[1024 * 8];
-#define GS_TICK(k)                                                                             \
-    do {                                                                                       \
-        if (threadIdx.x == 0 && blockIdx.x < 1024) g_split_ticks[blockIdx.x * 8 + (k)] = wall_clock64(); \
-    } while (0)
-#else
-#define GS_TICK(k) do { } while (0)
-#endif
-constexpr int GS_THREADS = 512;
-constexpr int GS_LDN = 104;       // LDS row of d1: 100 neurons, 16-byte aligned rows
-constexpr int GS_NCHK = 4;        // chunks of a slice held in registers
-template <typename T>
-struct SplitCfg {
-    static constexpr int CH = sizeof(T) == 4 ? 64 : 32;          // rows per chunk
-    static constexpr int BS_MAX = CH * GS_NCHK;                  // rows per slice
-    static constexpr size_t smem = 2 * (size_t)CH * (GS_LDN + 16) * sizeof(T);
-    // slices: whole groups of eight (one per XCD), each at most BS_MAX rows
-    static int slices(int B) { return ((B + BS_MAX - 1) / BS_MAX + 7) & ~7; }
-    static int slice_rows(int B) { return ((B + slices(B) - 1) / slices(B) + 3) & ~3; }
-    static size_t partial_elems(int B, int pout) { return (size_t)((pout + 15) / 16) * slices(B) * 7 * 256; }
-};
-constexpr int GS_CTR_INTS = TRAIN_ZERO_INTS;  // one arrival counter per p tile (at most 134: 448 bands)
-
-#ifndef CCNN_GS_WPE
-#define CCNN_GS_WPE 4    // waves per SIMD the registers must leave room for: two workgroups per compute unit
-#endif
-#ifndef CCNN_GS_CU
-#define CCNN_GS_CU 8     // rows in flight per thread in the column sums
-#endif
-template <typename T, int NO>
-__global__ __launch_bounds__(GS_THREADS, CCNN_GS_WPE) void grad_reduce_split(int B, int pout, int off_w1, int off_b1, int off_w2,
-                                                                int off_b2, const T *__restrict__ pool,
-                                                                const T *__restrict__ a1, const T *__restrict__ d1,
-                                                                const T *__restrict__ d2, const T *__restrict__ slab,
-                                                                int slab_rows, int npt, int nsl, int bs, int nb_w0,
-                                                                int nb_w2, int nb_b1, T *part1, unsigned *ctr,
-                                                                T *__restrict__ grad, UpdateRule<T> upd)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef typename Vec16<T>::type V;
-    constexpr int VW = Vec16<T>::W;
-    constexpr int CH = SplitCfg<T>::CH;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int no = NO ? NO : (off_b2 - off_w2) / H;
-    int blk = blockIdx.x;
-#if CCNN_SPLIT_PROBE == 1   // diagnostic builds: the dW1 workgroups alone / the column sums alone
-    if (blk >= npt * nsl) return;
-#elif CCNN_SPLIT_PROBE == 2
-    if (blk < npt * nsl) return;
-#endif
-    if (blk < npt * nsl) {
-        const int pt = blk / nsl, sl = blk - pt * nsl;   // nsl is a multiple of 8: slice sl runs on XCD sl mod 8
-        const int p0 = pt * 16;
-        GS_TICK(0);
-        const int b_lo = min(sl * bs, B), len = min(b_lo + bs, B) - b_lo;   // this slice's rows (none: a zero partial)
-        const int b_ld = min(b_lo, B - 1);                                  // (a valid row for the loads of an empty slice)
-        T *d1s = reinterpret_cast<T *>(smem);                  // [2][CH][GS_LDN]
-        T *pls = d1s + 2 * CH * GS_LDN;                        // [2][CH][16]
-        // ---- every load of the slice, before anything waits (clamped, unconditional) ----
-        constexpr int DV = CH * H / VW;                        // vectors of a d1 chunk (rows are contiguous in memory)
-        constexpr int DPT = (DV + GS_THREADS - 1) / GS_THREADS;
-        constexpr int PV = CH * 16 / VW;                       // vectors of a pool chunk
-        static_assert(PV <= GS_THREADS, "one pool vector per thread");
-        V dv[GS_NCHK][DPT], pv[GS_NCHK];
-        const V *d1v = reinterpret_cast<const V *>(d1 + (long)b_ld * H);
-        const long d1_last = (long)max(len, 1) * H / VW - 1;
-        const int pr = tid / (16 / VW), pc = tid % (16 / VW);   // pool chunk: row, vector of the row
-        const bool pcol_ok = p0 + pc * VW < pout;               // (pout is whole vectors)
-        const T *psrc = pool + (long)b_ld * pout + min(p0 + pc * VW, pout - VW);
-#pragma unroll
-        for (int c = 0; c < GS_NCHK; c++) {
-#pragma unroll
-            for (int u = 0; u < DPT; u++) dv[c][u] = d1v[min((long)c * DV + u * GS_THREADS + tid, d1_last)];
-            pv[c] = *reinterpret_cast<const V *>(psrc + (long)min(c * CH + pr, max(len, 1) - 1) * pout);
-        }
-        GS_TICK(1);
-        const int col = lane & 15, kq = lane >> 4;
-        const int n0 = wave * 16;
-        const bool nv = n0 + col < H;
-        typename Mma<T>::acc_t acc = {0, 0, 0, 0};
-        const int nchunks = (len + CH - 1) / CH;
-#pragma unroll
-        for (int c = 0; c < GS_NCHK; c++) {
-            if (c < nchunks) {
-                T *db = d1s + (c & 1) * CH * GS_LDN, *pb = pls + (c & 1) * CH * 16;
-#pragma unroll
-                for (int u = 0; u < DPT; u++) {
-                    const int e = u * GS_THREADS + tid;
-                    if (e < DV) {
-                        const int r = (e * VW) / H, cc = e * VW - r * H;
-                        V v = dv[c][u];
-                        if (c * CH + r >= len) v = V{};          // rows past the slice: zeros in the product
-                        *reinterpret_cast<V *>(db + r * GS_LDN + cc) = v;
-                    }
-                }
-                if (tid < PV) {
-                    V v = pv[c];
-                    if (c * CH + pr >= len || !pcol_ok) v = V{};
-                    *reinterpret_cast<V *>(pb + pr * 16 + pc * VW) = v;
-                }
-                // one barrier per chunk: whoever passes it has finished the products of chunk c - 1, so
-                // chunk c + 1 may overwrite that buffer
-                lds_barrier();
-                if (c == 0) GS_TICK(2);
-                if (wave < 7) {
-                    const T *ap = pb + kq * 16 + col, *bp = db + kq * GS_LDN + min(n0 + col, H - 1);
-#pragma unroll 8
-                    for (int k = 0; k < CH / 4; k++) {
-                        const T a = ap[4 * k * 16];
-                        const T b = bp[4 * k * GS_LDN];
-                        acc = Mma<T>::mma(a, nv ? b : T(0), acc);
-                    }
-                }
-            }
-        }
-        GS_TICK(3);
-        // ---- the slice's partial, written through; then arrive ----
-        T *mine = part1 + (((size_t)pt * nsl + sl) * 7 + (wave < 7 ? wave : 0)) * 256;
-        if (wave < 7) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) __hip_atomic_store(mine + r * 64 + lane, acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __builtin_amdgcn_s_waitcnt(0);   // this wave's stores are acknowledged
-        __shared__ unsigned last_flag;
-        __syncthreads();                  // ... and every wave's
-        GS_TICK(4);
-        if (tid == 0) {
-            const unsigned old = __hip_atomic_fetch_add(ctr + pt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last_flag = old == (unsigned)nsl - 1;
-            if (old == (unsigned)nsl - 1) __hip_atomic_store(ctr + pt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        GS_TICK(5);
-        if (!last_flag || wave >= 7) return;
-        // ---- last to arrive: the nsl partials in slice order, past the caches ----
-        const T *src = part1 + ((size_t)pt * nsl * 7 + wave) * 256 + lane;
-        T tot[4] = {0, 0, 0, 0};
-        for (int s0 = 0; s0 < nsl; s0 += 8) {
-            T v[8][4];
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-                    v[u][r] = __hip_atomic_load(src + (size_t)(s0 + u) * 7 * 256 + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) tot[r] = tot[r] + v[u][r];
-        }
-        GS_TICK(6);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int p = p0 + Mma<T>::row(lane, r), n = n0 + col;
-            if (p < pout && nv) upd.apply(grad, off_w1 + n + H * p, tot[r]);
-        }
-        GS_TICK(7);
-        return;
-    }
-    blk -= npt * nsl;
-    T *red = reinterpret_cast<T *>(smem);
-    if (blk < nb_w0) {
-        const int c = tid & 63, rg = tid >> 6;
-        const int k = min(blk * 64 + c, F * K + F - 1);
-        // (rows in flight per thread, measured at 2048 / 4096 samples: 4 -> 13.5 / 25.9 us for the launch,
-        // 8 -> 11.7 / 25.0, 16 -> 11.5 / 28.4, 32 -> 22.0 / 44.4: more is not better here)
-        const T tot = colsum8<T, CCNN_GS_CU>(slab_rows, rg, c, red, [&](int b) { return slab[(long)b * (F * K + F) + k]; });
-        if (rg == 0 && blk * 64 + c < F * K + F) upd.apply(grad, k, tot);   // partial layout = W0 | b0 = params[0..)
-        return;
-    }
-    blk -= nb_w0;
-    const int c = tid & 15, rg = tid >> 4;   // 16 columns x 32 row groups
-    auto colsum32 = [&](auto term) {
-        T acc = 0;
-        constexpr int CU = CCNN_GS_CU;   // rows in flight per thread
-        for (int b0 = rg; b0 < B; b0 += 32 * CU) {
-            T v[CU];
-#pragma unroll
-            for (int u = 0; u < CU; u++) {
-                const int b = b0 + 32 * u;
-                const T x = term(min(b, B - 1));   // clamped load, masked value
-                v[u] = b < B ? x : T(0);
-            }
-#pragma unroll
-            for (int u = 0; u < CU; u++) acc = acc + v[u];
-        }
-        red[rg * 16 + c] = acc;
-        __syncthreads();
-        T tot = 0;
-        if (rg == 0) {
-#pragma unroll
-            for (int r = 0; r < 32; r++) tot = tot + red[r * 16 + c];
-        }
-        return tot;
-    };
-    if (blk < nb_w2) {
-        const int k = min(blk * 16 + c, H * no - 1);   // k = o + classes * n
-        const int nn = k / no, o = k - nn * no;
-        const T tot = colsum32([&](int b) { return a1[(long)b * H + nn] * d2[(long)b * no + o]; });
-        if (rg == 0 && blk * 16 + c < H * no) upd.apply(grad, off_w2 + k, tot);
-    } else if (blk < nb_w2 + nb_b1) {
-        const int q = blk - nb_w2;
-        const int n = min(q * 16 + c, H - 1);
-        const T tot = colsum32([&](int b) { return d1[(long)b * H + n]; });
-        if (rg == 0 && q * 16 + c < H) upd.apply(grad, off_b1 + n, tot);
-    } else {
-        const int o = min(c, no - 1);
-        const T tot = colsum32([&](int b) { return d2[(long)b * no + o]; });
-        if (rg == 0 && c < no) upd.apply(grad, off_b2 + o, tot);
-    }
-}
-
 // ---------------------------------------------------------------------------
 // Which path a batch of B takes.  The fused per-sample kernel is a chain of latency-bound phases
-// that costs the same from 1 to 256 samples (one workgroup per CU) and then grows by the full
-// chain per 256 samples (every workgroup walks all of W1 twice).  The sample-tile kernel's chain is
-// half as long again for one sample but takes up to eight samples per workgroup at little more, and
-// reads W1 twice per TILE.  Measured crossovers fused -> tile: B = 257 (z = 103, fp32), 513
-// (z = 200, fp32), 480 (z = 176, fp64).  Where a tile holds so few samples that the batch needs
-// more than one round of workgroups (fp64, or fp32 beyond 200 bands: the LDS holds four samples)
-// the layer kernels win again from about 2000 samples (z = 176, fp64: 180 against 220 us at 2048).
+// that costs the same while all its workgroups fit the chip at once and then grows by the full
+// chain per round of workgroups (every workgroup walks W1).  The sample-tile kernel's chain is longer
+// for one sample but takes up to eight samples per workgroup at little more, and reads W1 twice per
+// TILE.  Measured crossovers fused -> tile: step_path() below.  Where a tile holds so few samples
+// that the batch needs more than one round of workgroups (fp64, or fp32 beyond 200 bands: the LDS
+// holds four samples) the layer kernels win again from about 2000 samples (z = 176, fp64: 181
+// against 192 us at 2048).
 constexpr int BATCHED_MIN_B = 768;          // fused -> layer kernels where no tile fits
 constexpr int BATCHED_MAX_PARTIALS = 256;   // workgroups (= partial gradient rows) of conv_bwd_batch
-constexpr int BATCHED_SPLIT_ROWS = 256;     // up to here one thread of grad_reduce sums all rows of the batch
-#ifndef CCNN_SPLIT_MIN_B
-#define CCNN_SPLIT_MIN_B 1536
-#endif
-constexpr int SPLIT_MIN_B = CCNN_SPLIT_MIN_B;   // from here the batch sums are split over workgroups as well (grad_reduce_split)
-// FUSED: sample_fwd_bwd + grad_reduce.  TILE: tile_fwd_bwd + grad_reduce / grad_reduce_big.
-// LAYERS: the four layer kernels + grad_reduce / grad_reduce_big (shapes whose tile does not fit the LDS).
+// FUSED: sample_fwd_bwd.  TILE: tile_fwd_bwd.  LAYERS: the four layer kernels (shapes whose tile does
+// not fit the LDS).  grad_reduce sums the batch and updates behind each of them.
 // CCNN_MBGD_PATH=fused|batched|tile|layers overrides the choice by batch size (tests run every
 // path on the same inputs; "batched" = whatever a large batch would take).
 enum class StepPath { FUSED, TILE, LAYERS };
@@ -1670,10 +1305,11 @@ inline StepPath step_path(int B, const ccnn_dims_t &d, TilePlan *plan, const Ste
     if (env.path == (int)StepPath::FUSED) return StepPath::FUSED;
     if (env.path == (int)StepPath::LAYERS) return StepPath::LAYERS;
     if (env.path == 3) return fits ? StepPath::TILE : StepPath::LAYERS;
-    // fp32: the fused kernel's time steps up where its workgroups stop fitting the chip at once - past
-    // 256 samples up to 128 bands (35 us at 288 against the tile kernel's 32), past 512 beyond (two
-    // workgroups per CU: 55 us at 512 and 74 at 576 against 57 and 63, 200 bands); fp64 as measured
-    const int tile_min_b = sizeof(T) == 8 ? 512 : d.z <= 128 ? 257 : 513;
+    // The fused kernel's time steps up where its workgroups stop fitting the chip at once: past 512
+    // samples in fp32 (two workgroups per CU; 103 bands: 29.4 us at 512 and 41.4 at 640 against the
+    // tile kernel's 33.5 and 36; 200 bands: 43.3 and 59.7 against 53.5 and 60.3), past 256 in fp64
+    // (176 bands: 46.4 us at 256 and 77.1 at 384 against 64.6 and 73.5)
+    const int tile_min_b = sizeof(T) == 8 ? 257 : 513;
     // one round of workgroups, or several rounds of FULL tiles at small band counts (fp32, B = 4096:
     // 110 us against the layer kernels' 120 at z = 103, but 210 against 198 at z = 224)
     const bool rounds_ok = tp.tiles <= 256 || (sizeof(T) == 4 && tp.ms == 8 && d.z <= 128);
@@ -1765,12 +1401,12 @@ template <typename T>
 struct MbgdWs {
     T *pool, *a1, *d1, *d2, *slab, *probs;
     unsigned long long *xch;   // fused path, forward pass split: [rows][2][H][PairWords] tagged words
+    static constexpr int XCH_MAX_B = 256;   // no device fits two workgroups per sample for more
     static size_t xch_words(int B) { return (size_t)8 * ((B + 7) / 8) * 2 * H * PairWords<T>::N; }
     // batched path only
-    T *dp, *gsum, *part1;
+    T *dp;
     unsigned char *px;
     int *ctr;
-    unsigned *rctr;   // arrival counters of grad_reduce_split
     StepPath path;
     TilePlan plan;   // path == TILE
     static int partial_rows(int B, StepPath path, const TilePlan &tp)   // rows of the conv-gradient partials
@@ -1787,7 +1423,7 @@ struct MbgdWs {
         const TilePlan &tp = sc.plan;
         if (path == StepPath::FUSED) {
             b += align_up((size_t)B * (F * K + F) * sizeof(T));     // per-sample conv gradient tiles
-            if (split_forward(B)) b += align_up(xch_words(B) * 8);
+            if (B <= XCH_MAX_B) b += align_up(xch_words(B) * 8);
         } else {
             const int G = partial_rows(B, path, tp);
             b += align_up((size_t)G * (F * K + F) * sizeof(T));     // per-workgroup conv gradient partials
@@ -1795,12 +1431,7 @@ struct MbgdWs {
                 b += align_up((size_t)B * d.pout * sizeof(T));      // dpool
                 b += align_up((size_t)B * d.pout);                  // pool winners, one byte each
             }
-            b += align_up((size_t)d.nparams * sizeof(T));           // summed gradient (multi-GPU exchange)
             b += align_up(TRAIN_CTR_INTS * sizeof(int));
-            if (B >= SPLIT_MIN_B) {
-                b += align_up(SplitCfg<T>::partial_elems(B, d.pout) * sizeof(T));   // dW1 partials per batch slice
-                b += align_up(GS_CTR_INTS * sizeof(unsigned));
-            }
         }
         return b;
     }
@@ -1812,16 +1443,16 @@ struct MbgdWs {
         d1 = c.take<T>((size_t)B * H);
         d2 = c.take<T>((size_t)B * d.n_classes);
         probs = c.take<T>((size_t)B * d.n_classes);
-        dp = gsum = part1 = nullptr;
+        dp = nullptr;
         xch = nullptr;
         px = nullptr;
         ctr = nullptr;
-        rctr = nullptr;
         path = sc.path;
         plan = sc.plan;
         if (path == StepPath::FUSED) {
             slab = c.take<T>((size_t)B * (F * K + F));
-            if (split_forward(B)) xch = c.take<unsigned long long>(xch_words(B));
+            if (B <= XCH_MAX_B) xch = c.take<unsigned long long>(xch_words(B));
+            if (!split_forward(B)) xch = nullptr;   // the region is there whatever the device (the size must not depend on one)
         } else {
             const int G = partial_rows(B, path, plan);
             slab = c.take<T>((size_t)G * (F * K + F));
@@ -1829,30 +1460,10 @@ struct MbgdWs {
                 dp = c.take<T>((size_t)B * d.pout);
                 px = c.take<unsigned char>((size_t)B * d.pout);
             }
-            gsum = c.take<T>((size_t)d.nparams);
             ctr = c.take<int>(TRAIN_CTR_INTS);
-            if (B >= SPLIT_MIN_B) {
-                part1 = c.take<T>(SplitCfg<T>::partial_elems(B, d.pout));
-                rctr = c.take<unsigned>(GS_CTR_INTS);
-            }
         }
     }
 };
-
-template <typename T>
-int exchange_update(ccnn_comm *cm, T *params, const T *grad, const UpdateRule<T> &upd, int z, long n, hipStream_t st);
-template <>
-int exchange_update<float>(ccnn_comm *cm, float *params, const float *grad, const UpdateRule<float> &upd, int z, long,
-                           hipStream_t st)
-{
-    return ccnn_allreduce_update_f32(cm, params, grad, upd.lr, z, upd.frozen_hi > upd.frozen_lo, st);
-}
-template <>
-int exchange_update<double>(ccnn_comm *cm, double *params, const double *grad, const UpdateRule<double> &upd, int,
-                            long n, hipStream_t st)
-{
-    return ccnn_allreduce_update_f64(cm, params, grad, upd.lr, upd.divisor, n, st);
-}
 
 // The two launches every path ends with share this: batch sums (+ update / exchange).
 template <typename T>
@@ -1900,7 +1511,7 @@ int mbgd_batched(const T *params, const T *cubes, const int *onehot, long first,
     const int G = MbgdWs<T>::partial_rows(B, w.path, w.plan);
     if (w.path == StepPath::TILE) {
         if (int e = tile_train<T, FLIP>(params, cubes, onehot, first, B, d, w.plan, w.pool, w.a1, w.d1, w.d2, probs,
-                                        loss_values, w.slab, w.rctr, st))
+                                        loss_values, w.slab, st))
             return e;
     } else {
     if (int e = train_forward<T, FLIP>(params, cubes, onehot, first, B, z, w.pool, w.px, w.a1, w.d1, w.d2, probs,
@@ -1922,39 +1533,11 @@ int mbgd_batched(const T *params, const T *cubes, const int *onehot, long first,
         const size_t smem = L.bytes(two ? 2 : 1);
         if (int e = allow_smem(kern, smem)) return e;
         launch("conv_bwd_batch", kern, dim3(G), dim3(CB_THREADS), smem, st, cubes, first, (const T *)w.dp,
-               (const T *)w.pool, (const unsigned char *)w.px, B, d.cube, d.re, d.mre, w.slab, w.rctr);
+               (const T *)w.pool, (const unsigned char *)w.px, B, d.cube, d.re, d.mre, w.slab);
         CCNN_LAUNCH_CHECK();
     }
     }
-    if (B <= BATCHED_SPLIT_ROWS) return launch_grad_reduce<T>(B, d, w, G, grad, upd, cm, st);
-    // large batches: the batch is split inside the workgroups of one launch (and, from SPLIT_MIN_B
-    // samples, over workgroups as well); across GPUs the launch stores the sum for the exchange + update kernel
-    {
-        const int nb_w0 = (F * K + F + 63) / 64;
-        const int nb_w2 = (H * d.n_classes + 15) / 16, nb_b1 = (H + 15) / 16;
-        const bool c13 = d.n_classes == CCNN_CLASSES;
-        T *gout = cm ? w.gsum : grad;
-        const UpdateRule<T> rule = cm ? UpdateRule<T>{} : upd;
-        if (w.part1) {
-            const int npt = (d.pout + 15) / 16, nsl = SplitCfg<T>::slices(B), bs = SplitCfg<T>::slice_rows(B);
-            launch("grad_reduce_split", c13 ? grad_reduce_split<T, CCNN_CLASSES> : grad_reduce_split<T, 0>,
-                   dim3(npt * nsl + nb_w0 + nb_w2 + nb_b1 + 1), dim3(GS_THREADS), SplitCfg<T>::smem, st, B, d.pout, d.off_w1,
-                   d.off_b1, d.off_w2, d.off_b2, (const T *)w.pool, (const T *)w.a1, (const T *)w.d1, (const T *)w.d2,
-                   (const T *)w.slab, G, npt, nsl, bs, nb_w0, nb_w2, nb_b1, w.part1, w.rctr, gout, rule);
-        } else {
-            const int nb_w1 = ((d.pout + 15) / 16 + 7) & ~7;   // p tiles in whole groups of eight
-            launch("grad_reduce_big", c13 ? grad_reduce_big<T, CCNN_CLASSES> : grad_reduce_big<T, 0>,
-                   dim3(7 * nb_w1 + nb_w0 + nb_w2 + nb_b1 + 1), dim3(GB_THREADS), 0, st, B, d.pout, d.off_w1, d.off_b1,
-                   d.off_w2, d.off_b2, (const T *)w.pool, (const T *)w.a1, (const T *)w.d1, (const T *)w.d2,
-                   (const T *)w.slab, G, nb_w1, nb_w0, nb_w2, nb_b1, gout, rule);
-        }
-        CCNN_LAUNCH_CHECK();
-    }
-    if (cm) {
-        if (!upd.params) return CCNN_E_INVALID;
-        return exchange_update<T>(cm, upd.params, w.gsum, upd, z, d.nparams, st);
-    }
-    return 0;
+    return launch_grad_reduce<T>(B, d, w, G, grad, upd, cm, st);
 }
 
 // grad != null: store the batch-summed gradient.  grad == null: apply `upd` in place.
@@ -2028,13 +1611,6 @@ int scratch_on_current_device(void **out)
     return 0;
 }
 }  // namespace
-
-#ifdef CCNN_SPLIT_TIMING
-extern "C" int ccnn_debug_split_ticks(unsigned long long *out)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_split_ticks), sizeof(unsigned long long) * 1024 * 8);
-}
-#endif
 
 #ifdef CCNN_FB_TIMING
 extern "C" int ccnn_debug_fb_ticks(unsigned long long *out)
@@ -2110,9 +1686,10 @@ int ccnn_mbgd_step_noalloc_f32(float *params, const float *cubes, const int *one
     // Every row of the scratch a step reads is written by the same step first, on every path, so
     // nothing has to be cleared between calls and what an earlier call left elsewhere is never
     // read: the fused kernel writes pool, a1, d1, d2 and one conv-gradient row for exactly the B
-    // samples grad_reduce then sums; the sample-tile kernel writes the same per-sample rows and one
-    // conv-gradient partial per TILE (a ragged last tile included), and grad_reduce_big sums exactly
-    // those `tiles` rows; the layer kernels zero their work counters inside their own launches.
+    // samples grad_reduce then sums (the words its workgroup pairs trade are cleared by their readers,
+    // and the array starts out zeroed); the sample-tile kernel writes the same per-sample rows and one
+    // conv-gradient partial per TILE (a ragged last tile included), and grad_reduce sums exactly those
+    // `tiles` rows; the layer kernels zero their work counters inside their own launches.
     // The regions' offsets move with B (MbgdWs carves them in order), which is harmless for the
     // same reason.
     UpdateRule<float> upd{params, lr, 0, d.off_b0, d.off_w1};

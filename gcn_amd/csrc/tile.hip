@@ -191,10 +191,8 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
                                                     const int *__restrict__ onehot, long first, int B, int ms, int nch,
                                                     ccnn_dims_t d, T *__restrict__ pool_g, T *__restrict__ a1_g,
                                                     T *__restrict__ d1_g, T *__restrict__ d2_g, T *__restrict__ probs_g,
-                                                    double *__restrict__ loss_values, T *__restrict__ part,
-                                                    unsigned *zero_ctr)
+                                                    double *__restrict__ loss_values, T *__restrict__ part)
 {
-    if (zero_ctr && blockIdx.x == 0 && threadIdx.x < TRAIN_ZERO_INTS) zero_ctr[threadIdx.x] = 0;   // for the batch sums that follow
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Vec16<T>::type V;
     constexpr int VW = Vec16<T>::W;
@@ -865,7 +863,7 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
 template <typename T, bool FLIP>
 int tile_train(const T *params, const T *cubes, const int *onehot, long first, int B, const ccnn_dims_t &d,
                const TilePlan &plan, T *pool, T *a1, T *d1, T *d2, T *probs, double *loss_values, T *part,
-               unsigned *zero_ctr, hipStream_t st)
+               hipStream_t st)
 {
     const bool c13 = d.n_classes == CCNN_CLASSES;
     auto kern = plan.nwv == 8 ? (c13 ? tile_fwd_bwd<T, FLIP, CCNN_CLASSES, 8> : tile_fwd_bwd<T, FLIP, 0, 8>)
@@ -875,15 +873,15 @@ int tile_train(const T *params, const T *cubes, const int *onehot, long first, i
     }
     if (int e = allow_smem(kern, plan.smem)) return e;
     launch("tile_fwd_bwd", kern, dim3(plan.tiles), dim3(64 * plan.nwv), plan.smem, st, params, cubes, onehot, first, B,
-           plan.ms, plan.nch, d, pool, a1, d1, d2, probs, loss_values, part, zero_ctr);
+           plan.ms, plan.nch, d, pool, a1, d1, d2, probs, loss_values, part);
     CCNN_LAUNCH_CHECK();
     return 0;
 }
 template int tile_train<float, true>(const float *, const float *, const int *, long, int, const ccnn_dims_t &,
                                      const TilePlan &, float *, float *, float *, float *, float *, double *, float *,
-                                     unsigned *, hipStream_t);
+                                     hipStream_t);
 template int tile_train<double, false>(const double *, const double *, const int *, long, int, const ccnn_dims_t &,
                                        const TilePlan &, double *, double *, double *, double *, double *, double *,
-                                       double *, unsigned *, hipStream_t);
+                                       double *, hipStream_t);
 
 }  // namespace ccnn

@@ -6,7 +6,6 @@
 namespace ccnn {
 
 constexpr int TRAIN_CTR_INTS = 8 * 32;   // work counters of the persistent forward kernels (zeroed by them per launch)
-constexpr int TRAIN_ZERO_INTS = 256;     // arrival counters of the split batch sums (cleared by the kernel before them)
 
 // conv + tanh + pool of samples [first, first + B) -> pool [B][pout] and px [B][pout] (which member
 // of each pool pair won, one byte), then FC1 + output layer + softmax -> a1 [B][100],
@@ -17,8 +16,7 @@ int train_forward(const T *params, const T *cubes, const int *onehot, long first
 
 // The whole per-sample part of a step in one launch, a tile of up to eight samples per workgroup
 // (tile.hip): pool, a1, d1, d2 rows (+ probs, loss_values) as train_forward leaves them, and one
-// conv-gradient partial [F K + F] per workgroup in part[plan.tiles][F K + F].  zero_ctr (optional):
-// TRAIN_ZERO_INTS words the launch clears for the batch-sum kernel that follows it in the step.
+// conv-gradient partial [F K + F] per workgroup in part[plan.tiles][F K + F].
 struct TilePlan {
     int nwv, ms, nch;   // waves per workgroup, samples per tile, position chunks of the delta image
     size_t smem;        // dynamic LDS bytes
@@ -36,6 +34,6 @@ int tile_waves_env();
 template <typename T, bool FLIP>
 int tile_train(const T *params, const T *cubes, const int *onehot, long first, int B, const ccnn_dims_t &d,
                const TilePlan &plan, T *pool, T *a1, T *d1, T *d2, T *probs, double *loss_values, T *part,
-               unsigned *zero_ctr, hipStream_t st);
+               hipStream_t st);
 
 }  // namespace ccnn

@@ -201,8 +201,8 @@ int ccnn_mbgd_step_f64(double *params, const double *cubes, const int *onehot, l
  * each other live in a fixed device array inside the library, CCNN_NOALLOC_SCRATCH_BYTES
  * per GPU, held until the process ends; a batch whose rows
  * (ccnn_mbgd_workspace_bytes(B, z, 4)) do not fit is rejected with CCNN_E_SCRATCH: 8 MiB
- * holds every B up to 1535 at z = 103, up to 457 at z = 200, up to 359 at z = 448 (larger
- * batches that take the sample-tile path keep fewer rows and can fit again, e.g. 513..996 at
+ * holds every B up to 1946 at z = 103, up to 457 at z = 200, up to 359 at z = 448 (larger
+ * batches that take the sample-tile path keep fewer rows and can fit again, e.g. 513..1142 at
  * z = 200: the size function tells).  The call makes no hipMalloc /
  * hipFree and uses no allocating library routine (keep ccnn_profile_enable off: the timing
  * hooks create events).  Results are bit-identical to ccnn_mbgd_step_f32.  All calls on one

@@ -49,8 +49,9 @@ def test_step_path_choice_needs_no_gpu(monkeypatch):
     monkeypatch.delenv("CCNN_MBGD_PATH", raising=False)
     assert lib.ccnn_mbgd_path(128, 103, 4) == 0            # the reference's batch sizes: one workgroup per sample
     assert lib.ccnn_mbgd_path(2048, 103, 4) == 1           # large batches: a tile of samples per workgroup
-    assert lib.ccnn_mbgd_path(256, 103, 4) == 0 and lib.ccnn_mbgd_path(300, 103, 4) == 1
+    assert lib.ccnn_mbgd_path(512, 103, 4) == 0 and lib.ccnn_mbgd_path(600, 103, 4) == 1
     assert lib.ccnn_mbgd_path(512, 200, 4) == 0 and lib.ccnn_mbgd_path(600, 200, 4) == 1
+    assert lib.ccnn_mbgd_path(256, 176, 8) == 0 and lib.ccnn_mbgd_path(300, 176, 8) == 1
     assert lib.ccnn_mbgd_path(2048, 448, 8) == 2           # no tile fits the LDS: one launch per layer
     assert lib.ccnn_mbgd_path(0, 103, 4) < 0 and lib.ccnn_mbgd_path(128, 103, 2) < 0
     fused = lib.ccnn_mbgd_workspace_bytes(2048, 103, 4)

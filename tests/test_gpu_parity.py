@@ -359,11 +359,10 @@ def test_mbgd_large_batches_match_oracle(dtype, z, B, lr, monkeypatch):
             parity.assert_groups(p_gpu.cpu().numpy(), refs[i0][1], d, TOL[dtype], f"parameters, path {path}, step {i0}")
 
 
-def test_split_batch_sums_do_not_depend_on_what_the_workspace_held(monkeypatch):
-    """From 1536 samples the batch sums are split over workgroups that count their arrivals in the
-    caller's workspace: the kernel before them clears the counters, so a workspace full of ones
-    (or of an earlier, differently sized call's rows) gives the same bits as a zeroed one - on the
-    sample-tile path and on the layer kernels."""
+def test_large_batch_step_does_not_depend_on_what_the_workspace_held(monkeypatch):
+    """A step of 1600 samples on the sample-tile path and on the layer kernels: a workspace full of
+    ones, or one that an earlier, larger call has used, gives the same bits as a zeroed one (every
+    row and counter a launch reads has been written or cleared inside the same step)."""
     z, B = 103, 1600
     params, cubes, onehot = make_problem(z, B, 31, np.float32)
     c_gpu, o_gpu = dev(cubes), dev(onehot)
@@ -384,7 +383,7 @@ def test_split_batch_sums_do_not_depend_on_what_the_workspace_held(monkeypatch):
             assert torch.equal(p_o, outs[0][0]) and torch.equal(lv_o, outs[0][1]), path
     p_ref = params.copy()
     lv_ref, _, _ = orc.mbgd_step(p_ref, cubes, onehot, 0, B, z, np.float32(0.002), want_grad=False)
-    parity.assert_groups(outs[0][0].numpy(), p_ref, orc.dims(z), 1e-5, "split batch sums")
+    parity.assert_groups(outs[0][0].numpy(), p_ref, orc.dims(z), 1e-5, "batch sums of 1600 samples")
 
 
 @pytest.mark.parametrize("dtype,z,B,lr", [(np.float32, 103, 128, 0.04), (np.float64, 176, 100, 0.5), (np.float32, 200, 37, 0.04)])

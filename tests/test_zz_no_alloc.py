@@ -18,12 +18,13 @@ def _p(t):
     return C.c_void_p(t.data_ptr())
 
 
-# (128, 37): the fused per-sample kernel, one scratch row per sample - rows 37..127 are stale in the
-# second call.  (600, 300): the sample-tile kernel + grad_reduce_big out of the same array - the
-# conv-gradient region then holds one partial row per TILE (75, then 38: a ragged last tile of four
-# samples) and sits at another offset for each batch size, so the second call reads rows the first
-# wrote at other places; every row a call reads it has written itself.
-@pytest.mark.parametrize("calls", [((0, 128), (128, 37)), ((0, 600), (600, 300))])
+# (128, 37): the fused per-sample kernel, two workgroups per sample that trade tagged words through the
+# array, one scratch row per sample - rows 37..127 are stale in the second call.  (400, 140): the same
+# kernel with one workgroup per sample, two per compute unit, then one per compute unit.  (1200, 600):
+# the sample-tile kernel out of the same array - the conv-gradient region then holds one partial row
+# per TILE (150, then 75) and sits at another offset for each batch size, so the second call reads
+# rows the first wrote at other places; every row a call reads it has written itself.
+@pytest.mark.parametrize("calls", [((0, 128), (128, 37)), ((0, 400), (400, 140)), ((0, 1200), (1200, 600))])
 def test_noalloc_step_equals_workspace_step_twice_second_smaller(calls):
     lib = L.load()
     z = 103
@@ -31,7 +32,7 @@ def test_noalloc_step_equals_workspace_step_twice_second_smaller(calls):
     rng = np.random.default_rng(5)
     n = calls[1][0] + calls[1][1]
     bmax = calls[0][1]
-    assert lib.ccnn_mbgd_path(bmax, z, 4) == (0 if bmax <= 256 else 1)
+    assert lib.ccnn_mbgd_path(bmax, z, 4) == (0 if bmax <= 512 else 1)
     cubes = torch.from_numpy(rng.random((n, 9 * z)).astype(np.float32)).cuda()
     onehot_h = np.zeros((n, 13), dtype=np.int32)
     onehot_h[np.arange(n), rng.integers(0, 13, n)] = 1
