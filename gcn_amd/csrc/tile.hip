@@ -39,8 +39,19 @@ extern "C" int ccnn_debug_tile_ticks(unsigned long long *out)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_ticks), sizeof(unsigned long long) * 32);
 }
+// ... and every workgroup its first instruction and the end of each of its waves ([block][0], [block][1 + wave])
+__device__ unsigned long long g_tile_wg[1024][17];
+#define TWG(slot)                                                                                       \
+    do {                                                                                                \
+        if (blockIdx.x < 1024 && (threadIdx.x & 63) == 0) g_tile_wg[blockIdx.x][slot] = wall_clock64(); \
+    } while (0)
+extern "C" int ccnn_debug_tile_wg(unsigned long long *out)   // [1024][17]
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_wg), sizeof(unsigned long long) * 1024 * 17);
+}
 #else
 #define TT(k) do { } while (0)
+#define TWG(slot) do { } while (0)
 #endif
 
 namespace ccnn {
@@ -221,6 +232,7 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
     const T *W1 = params + d.off_w1;
 
     TT(0);
+    if (threadIdx.x == 0) TWG(0);
     const T bias0 = params[d.off_b0 + col];
     const T biasx = params[d.off_b0 + 16 + (col & 3)];
     const int lab_g = onehot[(first + row) * no + min(lane, no - 1)];   // needed deep in the chain: fetched now
@@ -858,6 +870,7 @@ __global__ __launch_bounds__(64 * NWV) void tile_fwd_bwd(const T *__restrict__ p
         out[F * K + tid] = s / re;
     }
     TT(10);
+    TWG(1 + (threadIdx.x >> 6));
 }
 
 template <typename T, bool FLIP>

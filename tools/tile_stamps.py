@@ -35,3 +35,18 @@ print("  stage: small operands stored +%dns, barrier (first loads landed) +%dns,
       % tuple((t[k] - t[0]) * 10 for k in (11, 12, 13, 14, 15)))
 print("  shader clock per phase (GHz): " + "  ".join(
     f"{names[k]}={(t[21 + k] - t[20 + k]) / ((t[k + 1] - t[k]) * 10.0):.2f}" for k in range(10) if t[k + 1] > t[k]))
+if hasattr(lib, "ccnn_debug_tile_wg"):
+    w = (C.c_ulonglong * (1024 * 17))()
+    assert lib.ccnn_debug_tile_wg(w) == 0
+    a = np.array(w[:], dtype=np.int64).reshape(1024, 17)
+    a = a[a[:, 0] > 0]
+    t0 = a[:, 0].min()
+    start = (a[:, 0] - t0) / 100.0
+    ends = np.where(a[:, 1:] > 0, a[:, 1:], a[:, :1])
+    end = (ends.max(axis=1) - t0) / 100.0
+    dur = end - start
+    print(f"  {len(a)} workgroups: start median +{np.median(start):.2f} max +{start.max():.2f} us; own duration median {np.median(dur):.2f} "
+          f"min {dur.min():.2f} max {dur.max():.2f} us; last end +{end.max():.2f} us")
+    q = np.percentile(dur, [10, 50, 90, 99])
+    print(f"  durations p10 {q[0]:.2f} p50 {q[1]:.2f} p90 {q[2]:.2f} p99 {q[3]:.2f}; by XCD (block mod 8), median: "
+          + " ".join(f"{np.median(dur[i::8]):.1f}" for i in range(8)))
