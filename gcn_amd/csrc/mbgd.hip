@@ -841,8 +841,21 @@ __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int o
         const int col = lane & 15, kq = lane >> 4;
         // rows x columns of the tile: 16 pooled features x 16 neurons of dW1 (operands pool, d1), or, in
         // the last GR_NT tile workgroups, 16 neurons x the classes of dW2 (operands a1, d2)
-        const int pt = blk / GR_NT, nt = blk - pt * GR_NT;
-        const bool w2 = pt == nb_w1 / GR_NT - 1;
+        // consecutive workgroups go round the eight XCDs: the GR_NT tiles that share a row tile's operand
+        // (a p tile's 16 columns of pool) are dealt to ONE XCD, so that it reaches one L2 only - groups
+        // of 8 row tiles x GR_NT; the row tiles past the last whole group in plain order
+        const int nrt = nb_w1 / GR_NT, nrt8 = nrt & ~7;
+        int pt, nt;
+        if (blk < nrt8 * GR_NT) {
+            const int grp = blk / (8 * GR_NT), in = blk - grp * (8 * GR_NT);
+            pt = 8 * grp + (in & 7);
+            nt = in >> 3;
+        } else {
+            const int rest = blk - nrt8 * GR_NT;
+            pt = nrt8 + rest / GR_NT;
+            nt = rest - (rest / GR_NT) * GR_NT;
+        }
+        const bool w2 = pt == nrt - 1;
         const int nrow = w2 ? H : pout, ncol = w2 ? no : H;   // = the operands' row strides
         const int p0 = (w2 ? nt : pt) * 16, n0 = w2 ? 0 : nt * 16;
         const int obase = w2 ? off_w2 : off_w1;

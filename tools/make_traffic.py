@@ -41,7 +41,7 @@ def main():
     small = ("sample_fwd_bwd", "grad_reduce", "step_fused")
     large = ("tile_fwd_bwd", "grad_reduce")
     for fname, batch, dtype, kernels in (("pmc_hbm.csv", 128, "f32", small), ("pmc_hbm_b2048.csv", 2048, "f32", large),
-                                         ("pmc_hbm_f64_b100.csv", 100, "f64", small), ("pmc_hbm_f32_b512.csv", 512, "f32", large)):
+                                         ("pmc_hbm_f64_b100.csv", 100, "f64", small), ("pmc_hbm_f32_b512.csv", 512, "f32", small)):
         path = os.path.join(src, fname)
         if not os.path.exists(path):
             continue

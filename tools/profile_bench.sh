@@ -3,7 +3,7 @@
 #   bench.json (plain run, all extras), kernel_stats.csv (rocprofv3 --kernel-trace --stats of the
 #   headline run), pmc_hbm.csv (FETCH_SIZE / WRITE_SIZE, one pass each), pmc_sq.csv (SQ counters),
 #   the same three for the batched path at B = 2048 (tools/run_steps.py): *_b2048.csv, and the HBM
-#   counters alone for fp64 at B = 100 and fp32 at B = 512: pmc_hbm_f64_b100.csv, pmc_hbm_f32_b512.csv.
+#   counters alone for fp64 at B = 100 and fp32 at B = 512 (both the fused kernel): pmc_hbm_f64_b100.csv, pmc_hbm_f32_b512.csv.
 set -o pipefail
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1
 mkdir -p "$OUT"
@@ -28,7 +28,7 @@ timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d /tmp/pb_w2 -o p -- python3 $R 
 (python3 $T counters $(find /tmp/pb_f2 -name "*.db" | head -1) | grep "Kernel\|ccnn::"; python3 $T counters $(find /tmp/pb_w2 -name "*.db" | head -1) | grep "ccnn::") > "$OUT/pmc_hbm_b2048.csv"
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d /tmp/pb_s2 -o p -- python3 $R pavia_u 2048 60 > /dev/null 2>&1 || exit 1
 python3 $T counters $(find /tmp/pb_s2 -name "*.db" | head -1) | grep "Kernel\|ccnn::" > "$OUT/pmc_sq_b2048.csv"
-# the canonical fp64 trainer's batch, and the smallest batch of the sample-tile kernel: HBM bytes only
+# the canonical fp64 trainer's batch, and the largest batch of the fused kernel in fp32: HBM bytes only
 for W in "100 f64" "512 f32"; do
     set -- $W
     timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d /tmp/pb_f_$1 -o p -- python3 $R pavia_u $1 100 $2 > /dev/null 2>&1 || exit 1
