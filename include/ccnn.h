@@ -167,7 +167,13 @@ int ccnn_sgd_f64(double *params, const double *cubes, const int *onehot, long fi
  * gcn_mbgd_fp32.cu:925-1017) -- but with the per-sample gradient slabs already
  * summed over the batch: grad[k] = sum_i slab_i[k] (no lr, no 1/B).
  * loss_values [B] double, as loss_function writes them; probs [B][13] optional.
- * workspace: ccnn_mbgd_workspace_bytes(B, z, elem_size) bytes.
+ * workspace: ccnn_mbgd_workspace_bytes(B, z, elem_size) bytes (a function of its arguments only,
+ * never of a device); its contents need not be initialised and nothing in it has to survive from
+ * one call to the next, but calls that share a workspace must be ordered by one stream.  At batch
+ * sizes that leave the GPU half empty two workgroups share a sample and trade partial sums through
+ * the workspace; should one of them wait for its partner in vain (2 s: never seen), the sample's
+ * loss and every parameter of the step become NaN - a step that went wrong cannot pass for one
+ * that did not.
  * ccnn_mbgd_path: which implementation a batch of B takes (the results are the same to the
  * tolerances above; the choice is by speed): 0 = one workgroup per sample (the reference's
  * batch sizes), 1 = one workgroup per tile of up to eight samples (large batches), 2 = one launch
