@@ -96,5 +96,39 @@ int main()
         CK(hipEventElapsedTime(&ms, w0, w1));
         printf("first %3d x %3d threads, %5d B of LDS; second %3d x %3d: %.2f us per pair\n", sh.g1, sh.t1, sh.lds, sh.g2, sh.t2, ms / 2000 * 1e3);
     }
+    // the same pair without the second launch's wait for the first (any-order launch: what a kernel
+    // boundary costs beyond the dispatch itself), and 100 pairs per HIP graph launch
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(w0));
+    for (int i = 0; i < 2000; i++) {
+        hipLaunchKernelGGL(shaped<8>, dim3(256), dim3(512), 61440, 0, buf, 0);
+        hipExtLaunchKernelGGL(small, dim3(105), dim3(512), 0, 0, nullptr, nullptr, hipExtAnyOrderLaunch, buf);
+    }
+    CK(hipEventRecord(w1));
+    CK(hipEventSynchronize(w1));
+    CK(hipEventElapsedTime(&ms, w0, w1));
+    printf("second launch any-order: %.2f us per pair\n", ms / 2000 * 1e3);
+    for (int pairs : {1, 4, 100}) {
+        hipStream_t st;
+        CK(hipStreamCreate(&st));
+        hipGraph_t g;
+        hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < pairs; i++) {
+            hipLaunchKernelGGL(shaped<8>, dim3(256), dim3(512), 61440, st, buf, 0);
+            hipLaunchKernelGGL(small, dim3(105), dim3(512), 0, st, buf);
+        }
+        CK(hipStreamEndCapture(st, &g));
+        CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        CK(hipGraphLaunch(ge, st));
+        CK(hipStreamSynchronize(st));
+        CK(hipEventRecord(w0, st));
+        const int nl = 2000 / pairs;
+        for (int i = 0; i < nl; i++) CK(hipGraphLaunch(ge, st));
+        CK(hipEventRecord(w1, st));
+        CK(hipEventSynchronize(w1));
+        CK(hipEventElapsedTime(&ms, w0, w1));
+        printf("%d pair(s) per graph launch: %.2f us per pair\n", pairs, ms / (nl * pairs) * 1e3);
+    }
     return 0;
 }
