@@ -931,7 +931,10 @@ __global__ __launch_bounds__(GR_THREADS) void grad_reduce(int B, int pout, int o
         constexpr int WPV = sizeof(T) / 4;   // tagged words per value
         const int par = xstep & 1;
         const bool tile = lb < nb_w1;
-        const bool sender = tile ? tid < GR_TILE_VALUES : tid < 64;
+        // (threads whose value is padding - a tile's rows and columns past the matrix, a column-sum
+        // workgroup's lanes past its last column - trade nothing: the same threads on every rank, and
+        // an eighth of the bytes on the links)
+        const bool sender = (tile ? tid < GR_TILE_VALUES : tid < 64) && ok[0] >= 0;
         const int nv = 1;                    // values this thread trades
         const long word0 = (tile ? (long)lb * GR_TILE_VALUES + tid
                                  : (long)nb_w1 * GR_TILE_VALUES + (long)(lb - nb_w1) * 64 + tid) * WPV;
