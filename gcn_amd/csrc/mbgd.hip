@@ -214,9 +214,10 @@ __device__ __forceinline__ unsigned long long pair_word(unsigned bits, unsigned 
 }
 // Publishes `own` at out[0 .. N), takes the partner's value from in[0 .. N) and returns the sum of
 // the two in the order (first workgroup's) + (second workgroup's): the same bits in both.
-__device__ __forceinline__ float pair_sum(float own, unsigned long long *out, unsigned long long *in, unsigned tag, bool first)
+__device__ __forceinline__ float pair_sum(float own, unsigned long long *out, unsigned long long *in, unsigned tag, bool first,
+                                          bool publish = true)
 {
-    __hip_atomic_store(out, pair_word(__float_as_uint(own), tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (publish) __hip_atomic_store(out, pair_word(__float_as_uint(own), tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long t0 = wall_clock64();
     unsigned long long v;
     unsigned spins = 0;
@@ -230,11 +231,14 @@ __device__ __forceinline__ float pair_sum(float own, unsigned long long *out, un
     const float other = __uint_as_float((unsigned)(v >> 32));
     return first ? own + other : other + own;
 }
-__device__ __forceinline__ double pair_sum(double own, unsigned long long *out, unsigned long long *in, unsigned tag, bool first)
+__device__ __forceinline__ double pair_sum(double own, unsigned long long *out, unsigned long long *in, unsigned tag, bool first,
+                                           bool publish = true)
 {
     const unsigned long long bits = (unsigned long long)__double_as_longlong(own);
-    __hip_atomic_store(out, pair_word((unsigned)(bits >> 32), tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(out + 1, pair_word((unsigned)bits, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (publish) {
+        __hip_atomic_store(out, pair_word((unsigned)(bits >> 32), tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(out + 1, pair_word((unsigned)bits, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     const unsigned long long t0 = wall_clock64();
     unsigned long long hi, lo;
     unsigned spins = 0;
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
                                                       T *__restrict__ d2_g, T *__restrict__ probs_g,
                                                       double *__restrict__ loss_values,
                                                       T *__restrict__ slab, int d_rows,
-                                                      unsigned long long *__restrict__ xch, unsigned xtag)
+                                                      unsigned long long *__restrict__ xch, unsigned xtag, int xmute)
 {
     static_assert(!FS || SPLIT == 2, "the forward pass splits over the two workgroups of a sample");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -578,7 +582,9 @@ __global__ __launch_bounds__(NT, WPE) void sample_fwd_bwd(const T *__restrict__ 
             // zsum covers this workgroup's ten filters: add the partner's
             constexpr int XW = PairWords<T>::N;
             unsigned long long *xrow = xch + (size_t)row * (2 * H * XW);
-            zsum = pair_sum(zsum, xrow + (half * H + tid) * XW, xrow + ((half ^ 1) * H + tid) * XW, xtag, lead);
+            // (xmute: the test of the bounded wait - the second workgroup of every pair publishes nothing)
+            zsum = pair_sum(zsum, xrow + (half * H + tid) * XW, xrow + ((half ^ 1) * H + tid) * XW, xtag, lead,
+                            !(xmute && half == 1));
         }
         a = act(zsum + b1v);   // gcn_mbgd_fp64.cu:302
         a1s[tid] = a;
@@ -1584,7 +1590,8 @@ int mbgd_impl(const T *params, const T *cubes, const int *onehot, long first, in
     if (int e = allow_smem(fb, L.bytes)) return e;
     {
         launch("sample_fwd_bwd", fb, dim3(split ? 16 * ((B + 7) / 8) : B), dim3(FB_THREADS), L.bytes, st, params, cubes,
-               onehot, first, d, w.pool, w.a1, w.d1, w.d2, probs, loss_values, w.slab, B, w.xch, fs ? next_pair_tag() : 0u);
+               onehot, first, d, w.pool, w.a1, w.d1, w.d2, probs, loss_values, w.slab, B, w.xch, fs ? next_pair_tag() : 0u,
+               fs && getenv("CCNN_FB_TEST_MUTE_PARTNER") ? 1 : 0);
     }
     CCNN_LAUNCH_CHECK();
     return launch_grad_reduce<T>(B, d, w, B, grad, upd, cm, st);

@@ -420,6 +420,27 @@ def test_pair_exchange_does_not_depend_on_what_the_workspace_held(dtype, z, B, l
     parity.assert_groups(outs[0][0].numpy(), p_ref, orc.dims(z), TOL[dtype] * 3, "three steps through the pair exchange")
 
 
+def test_a_pair_whose_partner_never_answers_poisons_the_step(monkeypatch):
+    """CCNN_FB_TEST_MUTE_PARTNER makes the second workgroup of every pair publish nothing: the first
+    waits its two seconds, the call still returns, and the step cannot pass for a good one - every
+    loss value is a NaN, and so are the parameters the sample sums reach."""
+    z, B = 103, 16
+    params, cubes, onehot = make_problem(z, B, 47, np.float32)
+    p_gpu = dev(params)
+    monkeypatch.setenv("CCNN_FB_TEST_MUTE_PARTNER", "1")
+    lv = ops.mbgd_step(p_gpu, dev(cubes), dev(onehot), 0, B, z, 0.04)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("CCNN_FB_TEST_MUTE_PARTNER")
+    assert torch.isnan(lv).all()
+    d = orc.dims(z)
+    out = p_gpu.cpu().numpy()
+    assert np.isnan(out[d.off_w1:d.off_b1]).all() and np.isnan(out[d.off_w2:]).all()
+    # and the next step on the same workspace-less path is sound again
+    p2 = dev(params)
+    lv2 = ops.mbgd_step(p2, dev(cubes), dev(onehot), 0, B, z, 0.04)
+    assert torch.isfinite(lv2).all() and torch.isfinite(p2).all()
+
+
 def test_forward_pass_split_over_a_pair_agrees_with_the_unsplit_form(monkeypatch):
     """CCNN_FB_FSPLIT=0 keeps the whole forward pass in both workgroups of a sample (the form for
     launches that do not fit the chip at once); the split form adds the two halves of the hidden
