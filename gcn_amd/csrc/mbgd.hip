@@ -3,15 +3,17 @@
 // The reference runs 9 launches per sample on 100 streams and keeps per-sample
 // gradient slabs [B x params] (gcn_mbgd_fp64.cu:931-1064).  Here:
 //
-//   sample_fwd_bwd  one workgroup per sample does the whole per-sample chain with
+//   sample_fwd_bwd  one workgroup per sample - two, with ten filters each, while the whole
+//                   launch fits the GPU at once - does the whole per-sample chain with
 //                   the cube resident in LDS: conv (MFMA) -> tanh -> pool -> FC1 ->
 //                   FC2 -> softmax/loss -> delta2 -> delta1 -> delta at the pooled
 //                   features -> bp_maxpooling scatter -> conv gradient (MFMA).
 //                   It leaves pool, a1, delta1, delta2 and its conv-gradient tile
 //                   [F*K + F] in the workspace.
 //   grad_reduce     sums over the batch in the flat parameter layout:
-//                   dW1 = pool^T delta1 as an MFMA product with K = batch, the rest
-//                   as column sums; optionally applies the update in the same pass.
+//                   dW1 = pool^T delta1 and dW2 = a1^T delta2 as MFMA products with
+//                   K = batch (a 16 x 16 tile per workgroup), the rest as column sums;
+//                   optionally applies the update in the same pass.
 //
 // Only what differs between samples is per-sample; nothing of size [B x |W1|] exists.
 // A launch boundary costs about as much as one of these kernels' whole run, so the
