@@ -322,6 +322,31 @@ def test_mbgd_fused_step_matches_oracle(dtype, z, B, lr, mbgd_path):
             assert np.all(out[d.off_b0:d.off_w1] == 0)
 
 
+@pytest.mark.parametrize("dtype,z,batches", [
+    (np.float32, 103, (1, 2, 3, 7, 8, 9, 15, 17, 31, 33, 63, 65, 127, 129, 255, 256, 257, 511, 512, 513)),
+    (np.float64, 60, (1, 2, 5, 8, 9, 16, 17, 63, 65, 129, 255, 256, 257, 258)),
+    (np.float32, 200, (1, 6, 10, 130, 250, 257, 510))])
+def test_mbgd_step_at_the_edges_of_every_batch_split(dtype, z, batches):
+    """One step at each batch size around the places where the work is cut: a single sample, batches
+    below and just over the eight samples of one round of workgroups, sizes one off a multiple of the
+    16-sample product steps and of the eight-way split of the batch sum, the largest batch whose
+    samples are shared by two workgroups, and the sizes either side of the change of kernel."""
+    nmax = max(batches)
+    params, cubes, onehot = make_problem(z, nmax + 40, 5 + z, dtype)
+    d = orc.dims(z)
+    c_gpu, o_gpu = dev(cubes), dev(onehot)
+    ws = ops.Workspace()
+    lr = 0.04 if dtype == np.float32 else 0.5
+    for k, B in enumerate(batches):
+        i0 = k % 40                      # a different, unaligned start in the pool each time
+        p_ref = params.copy()
+        lv_ref, _, _ = orc.mbgd_step(p_ref, cubes, onehot, i0, B, z, dtype(lr / max(1, B // 64)), want_grad=False)
+        p_gpu = dev(params)
+        lv = ops.mbgd_step(p_gpu, c_gpu, o_gpu, i0, B, z, lr / max(1, B // 64), workspace=ws)
+        assert relerr(lv.cpu().numpy(), lv_ref) < TOL[dtype], B
+        parity.assert_groups(p_gpu.cpu().numpy(), p_ref, d, TOL[dtype], f"parameters, batch {B}")
+
+
 @pytest.mark.parametrize("dtype,z,B,lr", [(np.float32, 103, 301, 0.01),      # the smallest batches of the tile path: two samples per tile, the last one ragged
                                           (np.float32, 103, 2045, 0.002),    # full tiles of eight, the last one ragged
                                           (np.float32, 200, 1797, 0.002),    # full tiles, delta image in four chunks
